@@ -1,0 +1,168 @@
+#!/usr/bin/env python3
+"""bench.py -- nodes smoothed/sec + achieved HBM GB/s of the elliptic sweep (BASELINE.json metric).
+
+A step = ONE fused elliptic sweep of the workload (SURVEY.md 8d "unit of work"): the
+frozen-coefficient 9-point Winslow operator applied to both coordinate components of every
+node, with Jacobi scaling, the relaxation update, the perimeter (constraint / interface)
+rows and the residual-norm partial reduction -- i.e. one outer iteration of the `hip` solver
+in TM_INNER_RELAX mode, run through the C-ABI handle with the coordinates resident in HBM.
+
+  N = 1  : BASELINE configs[1] -- single synthetic 4096 x 4096 block, TFI seeded on the GPU.
+  N > 1  : weak scaling -- a strip of N such blocks stacked in i, one per GPU, coupled by
+           interface rows exchanged with torch.distributed (RCCL) point-to-point every sweep.
+
+Prints ONE JSON line on rank 0 (see the contract in the task description)."""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
+BYTES_PER_NODE = 32.0         # algorithmic traffic of a Laplace field sweep: read one double2, write one double2
+
+
+def cpu_baseline(n, budget_s=15.0):
+    """The oracle's matrix-free sweep (same arithmetic, -O2, single thread) on the host cores of this box,
+    on a bounded sample: whole 4096^2 sweeps until ~budget_s of CPU work."""
+    import numpy as np
+
+    from oracle import oracle
+
+    e_n = n
+    # seed on the CPU (oracle TFI) -- the baseline leg must not depend on the GPU
+    from turbomesh_amd import configs
+
+    def tfi_cpu(i_min, i_max, j_min, j_max):
+        return configs.block_from_array(oracle.tfi_block(i_min.points, i_max.points, j_min.points, j_max.points, i_min.clustering,
+                                                          i_max.clustering, j_min.clustering, j_max.clustering))
+
+    mesh = configs.single_block(e_n, e_n, tfi=tfi_cpu)
+    xy = mesh.blocks[0].points.data
+    t1 = oracle.time_relax_sweeps(xy, 1)          # warm-up + calibration
+    sweeps = max(1, min(64, int(budget_s / max(t1, 1e-3))))
+    t = oracle.time_relax_sweeps(xy, sweeps)
+    # reference-style inner iteration for context: assembled CSR + BiCGStab(diagonal), 2 mat-vecs per iteration
+    sub = configs.single_block(1024, 1024, tfi=tfi_cpu).blocks[0].points.data
+    tb, _ = oracle.time_bicgstab_iterations(sub, 4)
+    return {
+        "value": e_n * e_n * sweeps / t, "unit": "nodes/s", "cores": 1, "kind": "port",
+        "sample": f"{sweeps} Jacobi elliptic sweeps of the {e_n}x{e_n} block by the C++ oracle (g++ -O2 -ffp-contract=off, 1 thread, "
+                  f"{t:.1f} s); reference-style CSR BiCGStab(diagonal) on 1024^2: {1024 * 1024 * 8 / tb:.3e} node-matvecs/s",
+        "host_cpus": os.cpu_count(),
+    }
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--n", type=int, default=4096, help="block edge (nodes); 4096 is the BASELINE config")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--rows", type=int, default=0, help="K2 rows per chunk (tuning)")
+    ap.add_argument("--unroll", type=int, default=0, help="K2 row unroll (tuning)")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus != world:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+
+    from turbomesh_amd import _capi, configs
+    from turbomesh_amd.smoothing import smooth, solver
+
+    if args.rows or args.unroll:
+        _capi.lib().tm_tune_apply(args.rows, args.unroll)
+
+    n = args.n
+    dist = None
+    hooks_obj = None
+    if world > 1:
+        import torch.distributed as dist_mod
+
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        from turbomesh_amd import distributed as tmd
+
+        mesh = tmd.strip_for_rank(world, rank, n, n)                        # only the owned block carries coordinates
+        hooks_obj = tmd.TorchHooks(mesh, owner=list(range(world)), rank=rank, world=world,
+                                   option=solver.Option.hip(inner=solver.Inner.relax))
+        sm = hooks_obj.smoother
+        workload = f"strip of {world} blocks {n}x{n}, one per GPU, interface rows exchanged by RCCL p2p every sweep"
+    else:
+        mesh = configs.single_block(n, n)                                   # TFI on the GPU (K1)
+        sm = smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax), stream=torch.cuda.current_stream().cuda_stream)
+        workload = f"single synthetic {n}x{n} block, TFI seed, Laplace control function, fixed boundary (SURVEY 8d config 2)"
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    sm.iterate(args.warmup)
+    sm.profile(True)
+    barrier()
+    t0 = time.perf_counter()
+    st = sm.iterate(args.steps)
+    barrier()
+    dt = time.perf_counter() - t0
+    k2_ms, k2_launches = sm.profile_read()
+    sm.profile(False)
+
+    if dist is not None:
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    nodes_total = n * n * world
+    value = nodes_total * args.steps / dt
+
+    if rank == 0:
+        k2_avg_s = (k2_ms / 1e3) / max(1, k2_launches)
+        achieved = BYTES_PER_NODE * n * n / k2_avg_s / 1e9     # one K2 launch sweeps one block
+        traffic = None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
+        if os.path.exists(tpath):
+            try:
+                tj = json.load(open(tpath))
+                if tj.get("n") == n:
+                    traffic = tj.get("hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "nodes smoothed/sec (elliptic sweeps of the 4096^2 block) + achieved HBM GB/s",
+            "value": value, "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "nodes_per_gpu": n * n, "solver": "hip/relax (fused Jacobi elliptic sweep)", "omega": 1.0,
+                       "residual_last": st["last_residual"], "whole_job_GBps_algorithmic": BYTES_PER_NODE * value / 1e9},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
+                         "traffic": traffic, "kernel": "k_apply<RELAX,DELTA,field,laplace> (K2 winslow_apply)",
+                         "bytes_per_launch_algorithmic": BYTES_PER_NODE * n * n, "avg_launch_us": k2_avg_s * 1e6, "launches": k2_launches,
+                         "timing": "hipEvent pairs around every K2 launch on the handle's stream, inside the timed region"},
+        }
+        if not args.no_cpu_baseline and world == 1:
+            out["cpu_baseline"] = cpu_baseline(n)
+        elif not args.no_cpu_baseline:
+            out["cpu_baseline"] = None
+        print(json.dumps(out))
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

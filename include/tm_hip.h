@@ -1,0 +1,249 @@
+/*
+ * tm_hip.h -- C ABI of libtm_hip.so: MI355X (gfx950) structured-grid smoother for
+ * turbomesh's src/core hot path (2D linear TFI seeding + Winslow/Poisson elliptic block
+ * smoothing with inter-block coupling).
+ *
+ * Every entry point replaces one Zig-level seam of the reference (pascalPost/turbomesh);
+ * the seam is cited next to the declaration as reference file:line.  The Zig binding a
+ * maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all host arrays are caller-owned, never retained past
+ *     the call (handle API excepted: it keeps DEVICE copies only);
+ *   - coordinates are Vec2d = struct{data:[2]f64} slices reinterpret-cast to double*
+ *     (reference src/core/types.zig:16-37): x,y interleaved, node (i,j) at i*nj + j
+ *     (types.zig:94-96), 16 B per node;
+ *   - every function returns int: 0 = ok, >0 = warning status, <0 = tm_error; the message is
+ *     available from tm_last_error() (pattern: cg_get_error, reference src/core/cgns.zig:19-22);
+ *     nothing aborts the process;
+ *   - not re-entrant per handle; no hidden global state besides the HIP runtime.
+ */
+#ifndef TM_HIP_H
+#define TM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define TM_HIP_ABI_VERSION 1
+
+/* ------------------------------------------------------------------ errors */
+typedef enum tm_error {
+    TM_OK = 0,
+    TM_W_NOT_CONVERGED = 1,   /* warning only, like BiCGStab.zig:368-369 / GMRES.zig:422 */
+    TM_E_SIZE = -1,           /* error.InconsistentSize (tfi.zig:30)                       */
+    TM_E_TOPOLOGY = -2,       /* asserts of smooth.zig:562, 627-631, 719; boundary.zig:280 */
+    TM_E_MISMATCH = -3,       /* connectionDataCheck panic (smooth.zig:220-275)            */
+    TM_E_OVERFLOW = -4,       /* BoundedArray overflow (smooth.zig:1191-1206)              */
+    TM_E_UNSUPPORTED = -5,    /* error.ExternalSolverNotEnabled (solver.zig:48,56,82,89)   */
+    TM_E_ARG = -6,
+    TM_E_MEMORY = -7,
+    TM_E_HIP = -8,            /* HIP runtime failure / no gfx950 device                    */
+    TM_E_COMM = -9            /* exchange / all-reduce hook failed                         */
+} tm_error;
+
+const char* tm_last_error(void);
+int tm_abi_version(void);
+
+/* ------------------------------------------------------------------ data model
+ * POD mirrors of the reference types, enum values in declaration order. */
+enum { TM_SIDE_I_MIN = 0, TM_SIDE_I_MAX = 1, TM_SIDE_J_MIN = 2, TM_SIDE_J_MAX = 3 };   /* boundary.zig:8-13   */
+enum { TM_BC_WALL = 0, TM_BC_INLET = 1, TM_BC_OUTLET = 2 };                              /* boundary.zig:178-182 */
+
+typedef struct tm_range {        /* boundary.zig:15-19 */
+    uint64_t block;
+    uint32_t side;
+    uint32_t _pad;
+    uint64_t start, end;         /* inclusive; start > end = reversed */
+} tm_range;
+
+typedef struct tm_connection {   /* boundary.zig:119-123 */
+    tm_range r[2];
+    int32_t has_periodicity;     /* periodicity: ?Vec2d */
+    int32_t _pad;
+    double periodicity[2];       /* maps range[0] onto range[1] */
+} tm_connection;
+
+typedef struct tm_condition {    /* boundary.zig:184-187 */
+    tm_range range;
+    uint32_t kind;
+    uint32_t _pad;
+} tm_condition;
+
+typedef struct tm_block {        /* discrete.zig:138-141 + types.zig:78-80 */
+    double* xy;                  /* ni*nj*2 doubles, mutated in place by the smoother */
+    uint64_t ni, nj;             /* size[0], size[1] */
+} tm_block;
+
+typedef struct tm_mesh_desc {    /* discrete.zig:166-171 (names omitted) */
+    tm_block* blocks;
+    uint64_t nblocks;
+    tm_connection* conns;
+    uint64_t nconns;
+    tm_condition* bcs;
+    uint64_t nbcs;
+} tm_mesh_desc;
+
+/* wall_control_function.zig:10-20, 56-68 */
+enum { TM_CF_LAPLACE = 0, TM_CF_WHITE = 1 };
+typedef struct tm_control_fn {
+    int32_t kind;
+    int32_t _pad;
+    double ds_target;
+    double theta_target;
+} tm_control_fn;
+
+/* solver.zig:10-27: Tag in declaration order + the new `hip` member.  Only TM_SOLVER_HIP is
+ * served by this library; the reference's own tags return TM_E_UNSUPPORTED exactly like a
+ * build without -Duse-umfpack returns error.ExternalSolverNotEnabled. */
+enum { TM_SOLVER_GMRES = 0, TM_SOLVER_BICGSTAB = 1, TM_SOLVER_UMFPACK = 2, TM_SOLVER_PETSC = 3, TM_SOLVER_HIP = 4 };
+/* inner strategy of the hip solver */
+enum {
+    TM_INNER_BICGSTAB = 0,   /* Picard outer iteration (smooth.zig:104-154), each frozen-coefficient system solved by
+                                matrix-free BiCGStab on the row-equilibrated operator D^-1 A (replaces BiCGStab.zig:279-370) */
+    TM_INNER_RELAX = 1       /* every outer iteration is ONE fused Jacobi elliptic sweep X <- X + omega D^-1 (b - A(X) X)   */
+};
+typedef struct tm_solver_opt {
+    int32_t tag;             /* TM_SOLVER_* */
+    int32_t inner;           /* TM_INNER_* */
+    double rtol;             /* stop the inner solve at ||D^-1(b-Ax)||_2 <= max(atol, rtol*||D^-1 b||_2); 0 -> 1e-12 */
+    double atol;             /* 0 -> 0 */
+    uint64_t max_inner;      /* BiCGStab iteration cap per Picard solve; 0 -> 1000 (BiCGStab.zig:19) */
+    uint32_t check_every;    /* host convergence poll interval in inner iterations; 0 -> 8 */
+    uint32_t _pad;
+    double omega;            /* relaxation factor of TM_INNER_RELAX; 0 -> 1.0 */
+} tm_solver_opt;
+
+typedef struct tm_stats {
+    uint64_t outer_iterations;
+    uint64_t inner_iterations;   /* BiCGStab iterations summed over the outer iterations (both components advance together) */
+    uint64_t operator_sweeps;    /* applications of the 9-point operator to the whole mesh */
+    double last_residual;        /* (sum dx^2 + sum dy^2)^2 of the last outer iteration, smooth.zig:136 */
+    double last_dx2, last_dy2;   /* sum (x_old-x_new)^2, sum (y_old-y_new)^2, smooth.zig:112-134 */
+    double scaled_residual_rms;  /* sqrt(||D^-1(b - A(X)X)||^2 / (2*dof)) at the start of the last outer iteration */
+    double seconds;              /* wall time of the call, like smooth.zig:156-160 */
+    int32_t not_converged;       /* inner solves that hit max_inner */
+    int32_t _pad;
+} tm_stats;
+
+/* ------------------------------------------------------------------ seam 3: TFI
+ * Replaces tfi.linear2dBoundaryBlendedControlFunction (reference src/core/tfi.zig:112-208),
+ * called from Block2d.init (src/core/discrete.zig:146-157).  Host pointers; xy_out[ni*nj*2]
+ * is overwritten for ALL nodes (boundary nodes included, tfi.zig:164-205).
+ * s1,s2 [ni] / t1,t2 [nj]: clusterings of the i_min,i_max / j_min,j_max edges, first 0, last
+ * exactly 1 (tfi.zig:135-145) else TM_E_ARG; corner points must agree within 1e-10
+ * (tfi.zig:150-162) else TM_E_MISMATCH. */
+int tm_tfi_block(double* xy_out, uint64_t ni, uint64_t nj,
+                 const double* x_i_min, const double* x_i_max,   /* ni*2 each */
+                 const double* x_j_min, const double* x_j_max,   /* nj*2 each */
+                 const double* s1, const double* s2, const double* t1, const double* t2);
+
+/* Replaces tfi.linear2d (reference src/core/tfi.zig:19-67): plain TFI, xi=i/(ni-1), eta=j/(nj-1),
+ * corners from the i edges. */
+int tm_tfi_linear2d(double* xy_out, uint64_t ni, uint64_t nj,
+                    const double* e_i_min, const double* e_i_max, const double* e_j_min, const double* e_j_max);
+
+/* ------------------------------------------------------------------ seam 1: whole smoother
+ * Replaces smooth.mesh(allocator, *Mesh, iterations, solver.Option, Algorithm)
+ * (reference src/core/smoothing/smooth.zig:74-80); callers gui/main.zig:52, wasm/lib.zig:46-52.
+ * Mutates mesh->blocks[b].xy in place.  iterations == 0 is legal and leaves the mesh untouched. */
+int tm_smooth_mesh(const tm_mesh_desc* mesh, uint64_t iterations, const tm_solver_opt* opt,
+                   const tm_control_fn* cf, tm_stats* stats /* may be NULL */);
+
+/* ------------------------------------------------------------------ persistent handle
+ * Same smoother with the coordinates resident in HBM between calls (for callers that iterate,
+ * inspect, iterate ...).  create uploads the mesh; iterate runs `iterations` outer iterations on
+ * the device; download writes the current coordinates back into the caller's arrays. */
+typedef struct tm_smoother tm_smoother;
+
+/* Optional hooks that make ONE rank of a multi-GPU job out of a handle (one process per GPU):
+ * the mesh description handed to create() is the GLOBAL topology, `owner[b]` names the rank
+ * that owns block b, only owned blocks need coordinates.  exchange() must fill recv_buf (device)
+ * from the peers' send_buf (device) according to the plan returned by tm_smoother_exchange_plan;
+ * allreduce_sum() sums n doubles in place (device) over all ranks.  Both are enqueued on `stream`. */
+typedef struct tm_comm_hooks {
+    void* ctx;
+    int32_t rank, nranks;
+    const int32_t* owner;   /* [nblocks] */
+    int (*exchange)(void* ctx, const double* send_buf, double* recv_buf, void* stream);
+    int (*allreduce_sum)(void* ctx, double* buf, int32_t n, void* stream);
+    /* Optional caller-provided device memory (e.g. a torch tensor, so the hooks can hand views of it to
+     * torch.distributed): when workspace != NULL every device buffer of the handle is carved from it.
+     * Size it with tm_smoother_workspace_bytes. */
+    void* workspace;
+    uint64_t workspace_bytes;
+} tm_comm_hooks;
+/* Device bytes a handle for this mesh/options/partition needs (hooks may be NULL = single process). */
+int tm_smoother_workspace_bytes(const tm_mesh_desc* mesh, const tm_solver_opt* opt, const tm_control_fn* cf,
+                                const tm_comm_hooks* hooks, uint64_t* bytes);
+
+int tm_smoother_create(const tm_mesh_desc* mesh, const tm_solver_opt* opt, const tm_control_fn* cf,
+                       const tm_comm_hooks* hooks /* NULL = single process */, void* stream /* hipStream_t or NULL */,
+                       tm_smoother** out);
+int tm_smoother_iterate(tm_smoother* s, uint64_t iterations, tm_stats* stats);
+int tm_smoother_download(tm_smoother* s, const tm_mesh_desc* mesh);
+int tm_smoother_upload(tm_smoother* s, const tm_mesh_desc* mesh);
+void tm_smoother_destroy(tm_smoother* s);
+
+/* Exchange plan of a handle created with hooks: npeers peers; for peer k, send_count[k] rows
+ * (16 B each) start at send_offset[k] rows into send_buf, same for recv.  Rows are double2. */
+int tm_smoother_exchange_plan(const tm_smoother* s, int32_t* npeers, const int32_t** peer_rank,
+                              const int64_t** send_offset, const int64_t** send_count,
+                              const int64_t** recv_offset, const int64_t** recv_count);
+
+/* Introspection used by the parity tests (and by a Zig caller that wants the operator only):
+ * out = A(X) * in over the rank's owned rows, A assembled matrix-free from the CURRENT device
+ * coordinates; scaled != 0 applies the row equilibration D^-1.  in/out are host arrays with
+ * 2*dof doubles in global row order (smooth.zig:1643-1645).  Single-process handles only. */
+int tm_smoother_apply(tm_smoother* s, const double* in_xy, double* out_xy, int scaled);
+/* Right-hand side b (2*dof doubles) for the current coordinates (smooth.zig:780-921, 1060-1061). */
+int tm_smoother_rhs(tm_smoother* s, double* rhs_xy);
+/* Row kind per global row: -1 interior, else BlockBoundaryPointKind (smooth.zig:1168-1174). */
+int tm_smoother_row_kinds(const tm_smoother* s, int32_t* kinds /* [dof] */);
+uint64_t tm_smoother_dof(const tm_smoother* s);
+/* Current control function (P,Q) per node, 2*dof doubles (wall_control_function.zig:22-54). */
+int tm_smoother_control_function(tm_smoother* s, double* pq);
+
+/* Measurement support (bench.py roofline): when enabled, every K2 `winslow_apply` launch is bracketed by a
+ * pair of HIP events recorded on the handle's stream; read returns the summed elapsed milliseconds and the
+ * number of launches since the last read (and resets both). */
+int tm_smoother_profile(tm_smoother* s, int enable);
+int tm_smoother_profile_read(tm_smoother* s, double* k2_ms_total, uint64_t* k2_launches);
+
+/* ------------------------------------------------------------------ host-only planning (no GPU needed)
+ * The perimeter-row table the device kernels consume, exported as CSR so it can be compared with
+ * the reference's assembled rows (smooth.zig:421-921).  Only sizes/topology are read from `mesh`
+ * (coordinates may be NULL).  Arrays are malloc'ed by the library; free with tm_plan_free. */
+typedef struct tm_plan_rows {
+    uint64_t nrows;          /* number of perimeter rows of the whole mesh                         */
+    int64_t* row;            /* [nrows] global row id, ascending                                   */
+    int32_t* kind;           /* [nrows] BlockBoundaryPointKind                                     */
+    int32_t* ncols;          /* [nrows]                                                            */
+    int64_t* cols;           /* [nrows*9] global column ids, ascending                             */
+    double* coef_x;          /* [nrows*9] x-system coefficients (NaN for `smoothed` rows: dynamic) */
+    double* coef_y;          /* [nrows*9] y-system coefficients                                    */
+    double* rhs;             /* [nrows*2] static rhs (NaN where it is taken from the coordinates)  */
+    int32_t* slot;           /* [nrows*9] smoothed rows: StencilData index (smooth.zig:175-185) per column */
+} tm_plan_rows;
+int tm_plan_build(const tm_mesh_desc* mesh, tm_plan_rows* out);
+void tm_plan_free(tm_plan_rows* rows);
+
+/* ------------------------------------------------------------------ device-level entry points
+ * Same kernels on caller-provided DEVICE pointers and stream, for callers that keep blocks in
+ * HBM (bench.py, the multi-GPU driver).  No allocation, no synchronisation. */
+int tm_dev_tfi_block(double* d_xy, uint64_t ni, uint64_t nj,
+                     const double* d_x_i_min, const double* d_x_i_max, const double* d_x_j_min, const double* d_x_j_max,
+                     const double* d_s1, const double* d_s2, const double* d_t1, const double* d_t2, void* stream);
+/* One fused Jacobi elliptic sweep of a single block with fixed boundary (Laplace control function):
+ * d_out = d_in + omega * D^-1 (b - A(d_in) d_in) on interior nodes, boundary nodes copied;
+ * d_partials[2*nwg] receives per-workgroup sums of (dx^2, dy^2); returns nwg through *nwg. */
+int tm_dev_relax_sweep(const double* d_in, double* d_out, uint64_t ni, uint64_t nj, double omega,
+                       double* d_partials, uint64_t partials_capacity, uint64_t* nwg, void* stream);
+uint64_t tm_dev_relax_partials_needed(uint64_t ni, uint64_t nj);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TM_HIP_H */

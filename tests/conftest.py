@@ -1,0 +1,76 @@
+"""pytest configuration: the `gpu` marker + shared helpers.
+
+GPU tests (`-m gpu`) call the HIP path through the C-ABI and compare with the CPU oracle;
+CPU tests (`-m "not gpu"`) cover the oracle against known answers / golden vectors, the host
+planning logic, the multi-rank plumbing (gloo) and that libtm_hip.so exports its ABI."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+
+
+def _has_gpu():
+    try:
+        import torch
+
+        return torch.cuda.is_available()
+    except Exception:
+        return False
+
+
+def pytest_collection_modifyitems(config, items):
+    if _has_gpu():
+        return
+    skip = pytest.mark.skip(reason="no GPU in this container")
+    for item in items:
+        if "gpu" in item.keywords:
+            item.add_marker(skip)
+
+
+@pytest.fixture(scope="session", autouse=True)
+def _built():
+    """Make sure the oracle and the HIP library exist (built by __graft_entry__.build())."""
+    from oracle import oracle
+
+    oracle.build()
+    lib = os.path.join(ROOT, "turbomesh_amd", "libtm_hip.so")
+    if not os.path.exists(lib):
+        import __graft_entry__ as g
+
+        g.build()
+
+
+class OracleMesh:
+    """Duck-typed mesh for oracle.py built from a turbomesh_amd.discrete.Mesh (deep copy of the coordinates)."""
+
+    def __init__(self, mesh):
+        self.blocks = [np.array(b.points.data, dtype=np.float64, order="C", copy=True) for b in mesh.blocks]
+        self.connections = [((c.ranges[0].block, int(c.ranges[0].side), c.ranges[0].start, c.ranges[0].end),
+                             (c.ranges[1].block, int(c.ranges[1].side), c.ranges[1].start, c.ranges[1].end),
+                             None if c.periodicity is None else tuple(c.periodicity)) for c in mesh.connections]
+        self.bcs = [((b.range.block, int(b.range.side), b.range.start, b.range.end), int(b.kind)) for b in mesh.boundary_conditions]
+
+    def flat(self):
+        return np.concatenate([b.reshape(-1, 2) for b in self.blocks], axis=0)
+
+
+def oracle_tfi(i_min, i_max, j_min, j_max):
+    """TFI callable for turbomesh_amd.configs builders that runs on the CPU oracle (CPU-only tests)."""
+    from oracle import oracle
+    from turbomesh_amd.configs import block_from_array
+
+    return block_from_array(oracle.tfi_block(i_min.points, i_max.points, j_min.points, j_max.points, i_min.clustering, i_max.clustering,
+                                             j_min.clustering, j_max.clustering))
+
+
+def mesh_flat(mesh):
+    return np.concatenate([b.points.data.reshape(-1, 2) for b in mesh.blocks], axis=0)

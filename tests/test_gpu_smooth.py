@@ -1,0 +1,163 @@
+"""Smoother parity on the MI355X: Picard iterates and converged coordinates vs the oracle.
+
+Oracle semantics = the reference with an exact linear solve per outer iteration (its UMFPACK
+backend, umfpack.zig:18-24): oracle-assembled CSR + scipy splu.  The GPU solves the same frozen
+systems with matrix-free BiCGStab to rtol 1e-13 on the row-scaled residual, so every iterate
+must agree to <= 1e-10 RMS (BASELINE.json tolerance, fp64)."""
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.conftest import OracleMesh, mesh_flat
+from tests.meshes import TOPOLOGIES
+from turbomesh_amd import configs
+from turbomesh_amd.smoothing import smooth, solver, wall_control_function as wcf
+
+pytestmark = pytest.mark.gpu
+TOL_RMS = 1e-10
+
+
+def _rms(a, b):
+    return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+@pytest.mark.parametrize("name", list(TOPOLOGIES))
+def test_picard_iterates_match_exact_oracle(name):
+    mesh = TOPOLOGIES[name]()
+    om = OracleMesh(mesh)
+    hist, iterates = oracle.picard_exact(om, 3, keep_iterates=True)
+    with smooth.Smoother(mesh, solver.Option.hip(rtol=1e-13, max_inner=5000)) as sm:
+        for k in range(3):
+            st = sm.iterate(1)
+            assert st["not_converged"] == 0, st
+            sm.download()
+            ref = np.concatenate([b.reshape(-1, 2) for b in iterates[k]])
+            assert _rms(mesh_flat(mesh), ref) <= TOL_RMS, (name, k, _rms(mesh_flat(mesh), ref))
+            # the reference's logged residual (sum dx^2 + sum dy^2)^2, smooth.zig:136
+            assert st["last_residual"] == pytest.approx(hist[k], rel=1e-6, abs=1e-30)
+
+
+def test_smooth_mesh_seam_equals_handle_and_zero_iterations():
+    mesh = TOPOLOGIES["strip3_9x12"]()
+    before = mesh_flat(mesh).copy()
+    st = smooth.mesh(mesh, 0, solver.Option.hip())   # iterations == 0 is legal and returns the TFI mesh untouched
+    assert st["outer_iterations"] == 0 and np.array_equal(mesh_flat(mesh), before)
+    om = OracleMesh(mesh)
+    oracle.picard_exact(om, 4)
+    st = smooth.mesh(mesh, 4, solver.Option.hip(rtol=1e-13))
+    assert st["outer_iterations"] == 4 and st["operator_sweeps"] > 0
+    assert _rms(mesh_flat(mesh), om.flat()) <= TOL_RMS
+
+
+def test_constraint_rows_known_answers():
+    # fixed rows return boundary coordinates bit-exactly; connected rows x1 = x0 + periodicity;
+    # junction node = mean of its neighbours; sliding rows: x unchanged, y equals the first interior y.
+    mesh = TOPOLOGIES["channel_periodic_sliding"]()
+    before = mesh.blocks[0].points.data.copy()
+    smooth.mesh(mesh, 2, solver.Option.hip(rtol=1e-13))
+    d = mesh.blocks[0].points.data
+    np.testing.assert_allclose(d[:, -1], d[:, 0] + np.array([0.0, 0.8]), rtol=0, atol=1e-12)       # periodic partner
+    assert np.array_equal(d[0, 1:-1, 0], before[0, 1:-1, 0])                                       # sliding: x kept
+    np.testing.assert_allclose(d[0, 1:-1, 1], d[1, 1:-1, 1], rtol=0, atol=1e-12)                   # sliding: y = first interior y
+    assert np.array_equal(d[-1, :], before[-1, :])                                                 # fixed outlet bit-exact
+    mesh = TOPOLOGIES["two_by_two_junction"]()
+    fixed_before = [b.points.data[0, :].copy() for b in mesh.blocks[:2]]
+    smooth.mesh(mesh, 2, solver.Option.hip(rtol=1e-13))
+    b0, b1, b2, b3 = (b.points.data for b in mesh.blocks)
+    assert np.array_equal(b0[0, :], fixed_before[0])                                               # fixed outer wall bit-exact
+    centre = b0[-1, -1]
+    nb = (b0[-2, -2] + b1[1, -2] + b2[-2, 1] + b3[1, 1]) / 4.0
+    np.testing.assert_allclose(centre, nb, rtol=0, atol=1e-12)                                     # junction = mean of neighbours
+    for other in (b1[0, -1], b2[-1, 0], b3[0, 0]):
+        np.testing.assert_allclose(other, centre, rtol=0, atol=1e-13)                              # overlapping corners follow
+
+
+def test_affine_grid_is_a_fixed_point():
+    # any affine image of a uniform grid solves the Laplace system: first residual ~ 0,
+    # and a perturbed interior returns to it.
+    ni, nj = 19, 23
+    i, j = np.meshgrid(np.arange(ni) / (ni - 1), np.arange(nj) / (nj - 1), indexing="ij")
+    grid = np.stack([1.0 + 2.0 * i + 0.3 * j, -0.5 + 0.4 * i + 1.5 * j], axis=2)
+    from turbomesh_amd.discrete import Mesh
+
+    m = Mesh()
+    m.addBlock("affine", configs.block_from_array(grid.copy()))
+    st = smooth.mesh(m, 1, solver.Option.hip(rtol=1e-13))
+    assert st["scaled_residual_rms"] < 1e-15 and st["last_residual"] < 1e-50
+    rng = np.random.default_rng(0)
+    m.blocks[0].points.data[1:-1, 1:-1] += 0.2 / ni * (rng.random((ni - 2, nj - 2, 2)) - 0.5)
+    smooth.mesh(m, 25, solver.Option.hip(rtol=1e-13))
+    assert _rms(m.blocks[0].points.data, grid) < 1e-11
+
+
+def test_relax_sweep_bit_exact_and_same_fixed_point():
+    # one fused Jacobi sweep == the oracle's matrix-free sweep, bit for bit (single block, fixed boundary)
+    mesh = configs.single_block(33, 47, perturb=0.25)
+    ref = mesh.blocks[0].points.data.copy()
+    oracle.time_relax_sweeps(ref, 3, 1.0)
+    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+        st = sm.iterate(3)
+        sm.download()
+    assert mesh.blocks[0].points.data.tobytes() == ref.tobytes()
+    assert st["operator_sweeps"] == 3 and st["last_residual"] > 0
+    # relaxation and Picard share the fixed point A(X) X = b
+    mesh_a = configs.single_block(17, 17, perturb=0.25)
+    mesh_b = configs.single_block(17, 17, perturb=0.25)
+    smooth.mesh(mesh_a, 40, solver.Option.hip(rtol=1e-13))
+    with smooth.Smoother(mesh_b, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+        for _ in range(40):
+            st = sm.iterate(250)
+            if st["scaled_residual_rms"] < 1e-14:
+                break
+        sm.download()
+    assert _rms(mesh_flat(mesh_a), mesh_flat(mesh_b)) <= TOL_RMS
+
+
+def test_relax_multiblock_converges_to_picard_fixed_point():
+    mesh_a = TOPOLOGIES["two_by_two_junction"]()
+    mesh_b = TOPOLOGIES["two_by_two_junction"]()
+    smooth.mesh(mesh_a, 40, solver.Option.hip(rtol=1e-13))
+    with smooth.Smoother(mesh_b, solver.Option.hip(inner=solver.Inner.relax, omega=0.9)) as sm:
+        for _ in range(60):
+            st = sm.iterate(250)
+            if st["scaled_residual_rms"] < 1e-14:
+                break
+        sm.download()
+    assert _rms(mesh_flat(mesh_a), mesh_flat(mesh_b)) <= TOL_RMS
+
+
+def test_white_control_function_picard():
+    # wall control function (wall_control_function.zig:70-473) on the smallest layout it supports
+    mesh = TOPOLOGIES["plate_le"]()
+    om = OracleMesh(mesh)
+    control = ("white", 0.02, 0.5 * np.pi)
+    oracle.picard_exact(om, 4, control=control)
+    with smooth.Smoother(mesh, solver.Option.hip(rtol=1e-13, max_inner=5000), wcf.Algorithm(wcf.White(0.02))) as sm:
+        st = sm.iterate(4)
+        sm.download()
+        assert st["not_converged"] == 0
+    assert _rms(mesh_flat(mesh), om.flat()) <= 1e-9   # P,Q pass through acos/atan2 (libm vs ocml): looser than the Laplace bar
+
+
+def test_full_size_sweep_properties():
+    # BASELINE config 2 size (4096^2): properties that do not need a CPU run of the same size.
+    n = 4096
+    mesh = configs.single_block(n, n)
+    boundary = [mesh.blocks[0].points.data[0].copy(), mesh.blocks[0].points.data[-1].copy(), mesh.blocks[0].points.data[:, 0].copy(),
+                mesh.blocks[0].points.data[:, -1].copy()]
+    sub = mesh.blocks[0].points.data[1000:1067, 2000:2131].copy()   # a window for an oracle cross-check
+    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+        st1 = sm.iterate(1)
+        sm.download()
+        d = mesh.blocks[0].points.data
+        assert not np.isnan(d).any()
+        # fixed boundary returned bit-exactly
+        assert np.array_equal(d[0], boundary[0]) and np.array_equal(d[-1], boundary[1]) and np.array_equal(d[:, 0], boundary[2]) and np.array_equal(d[:, -1], boundary[3])
+        # interior of the window equals one oracle sweep of the window (its own boundary acts as halo)
+        ref = sub.copy()
+        oracle.time_relax_sweeps(ref, 1, 1.0)
+        assert np.array_equal(d[1001:1066, 2001:2130], ref[1:-1, 1:-1])
+        # the fused residual norm decreases monotonically over sweeps of a smooth TFI seed
+        st2 = sm.iterate(20)
+        assert 0 < st2["last_residual"] < st1["last_residual"]
+        assert st2["operator_sweeps"] == 20

@@ -1,0 +1,372 @@
+// extern "C" surface of libtm_hip.so (declared in include/tm_hip.h).
+#include "tm_smoother.hpp"
+#include <cmath>
+#include <cstdlib>
+#include <cstring>
+#include <limits>
+#include <memory>
+
+using namespace tmh;
+
+static thread_local std::string g_last_error;
+
+template <class F>
+static int guarded(F&& f) {
+    try {
+        return f();
+    } catch (const TmError& e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const PlanError& e) {
+        g_last_error = e.what();
+        return e.code;
+    } catch (const std::bad_alloc&) {
+        g_last_error = "out of host memory";
+        return TM_E_MEMORY;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return TM_E_ARG;
+    }
+}
+#define HIPCHK(x) hip_check((x), #x)
+
+static void require_gfx950() {
+    static int checked = 0;
+    if (checked) return;
+    int dev = 0;
+    HIPCHK(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIPCHK(hipGetDeviceProperties(&prop, dev));
+    if (std::strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+        throw TmError(TM_E_HIP, std::string("libtm_hip is built for gfx950 (MI355X) only, found ") + prop.gcnArchName);
+    checked = 1;
+}
+
+// RAII device buffer for the host-pointer entry points
+struct DevBuf {
+    void* p = nullptr;
+    explicit DevBuf(size_t bytes) {
+        if (hipMalloc(&p, bytes ? bytes : 256) != hipSuccess) throw TmError(TM_E_MEMORY, "hipMalloc failed");
+    }
+    ~DevBuf() { (void)hipFree(p); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    template <class T>
+    T* as() { return static_cast<T*>(p); }
+};
+
+static bool close2(const double* a, const double* b, double tol) { return std::fabs(a[0] - b[0]) <= tol && std::fabs(a[1] - b[1]) <= tol; }
+
+extern "C" {
+
+const char* tm_last_error(void) { return g_last_error.c_str(); }
+int tm_abi_version(void) { return TM_HIP_ABI_VERSION; }
+
+// internal tuning knob used by the benchmark sweeps (not part of the drop-in surface)
+int tm_tune_apply(int rows_per_chunk, int unroll) {
+    tune_apply(rows_per_chunk, unroll);
+    return TM_OK;
+}
+
+// ------------------------------------------------------------------ TFI (tfi.zig:112-208)
+int tm_tfi_block(double* xy_out, uint64_t ni, uint64_t nj, const double* x_i_min, const double* x_i_max, const double* x_j_min,
+                 const double* x_j_max, const double* s1, const double* s2, const double* t1, const double* t2) {
+    return guarded([&]() {
+        if (!xy_out || !x_i_min || !x_i_max || !x_j_min || !x_j_max || !s1 || !s2 || !t1 || !t2) throw TmError(TM_E_ARG, "null argument");
+        if (ni < 2 || nj < 2 || ni * nj >= (uint64_t{1} << 31)) throw TmError(TM_E_SIZE, "InconsistentSize: block must be at least 2 x 2 and below 2^31 nodes");
+        // the reference's debug asserts (tfi.zig:135-162) become error codes
+        if (s1[0] != 0 || s1[ni - 1] != 1.0 || s2[0] != 0 || s2[ni - 1] != 1.0 || t1[0] != 0 || t1[nj - 1] != 1.0 || t2[0] != 0 ||
+            t2[nj - 1] != 1.0)
+            throw TmError(TM_E_ARG, "clusterings must start at 0 and end at exactly 1 (tfi.zig:135-145)");
+        const double tol = 1e-10;
+        if (!close2(x_i_min, x_j_min, tol) || !close2(x_i_min + 2 * (ni - 1), x_j_max, tol) || !close2(x_j_min + 2 * (nj - 1), x_i_max, tol) ||
+            !close2(x_i_max + 2 * (ni - 1), x_j_max + 2 * (nj - 1), tol))
+            throw TmError(TM_E_MISMATCH, "edge end points do not meet at the block corners (tfi.zig:150-162)");
+        require_gfx950();
+        const size_t ei = sizeof(double) * 2 * ni, ej = sizeof(double) * 2 * nj;
+        DevBuf out(sizeof(double) * 2 * ni * nj), a(ei), b(ei), c(ej), d(ej), ds1(ei / 2), ds2(ei / 2), dt1(ej / 2), dt2(ej / 2);
+        HIPCHK(hipMemcpy(a.p, x_i_min, ei, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b.p, x_i_max, ei, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c.p, x_j_min, ej, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d.p, x_j_max, ej, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ds1.p, s1, ei / 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(ds2.p, s2, ei / 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dt1.p, t1, ej / 2, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dt2.p, t2, ej / 2, hipMemcpyHostToDevice));
+        HIPCHK(launch_tfi_block(out.as<double2>(), static_cast<int>(ni), static_cast<int>(nj), a.as<double2>(), b.as<double2>(), c.as<double2>(),
+                                d.as<double2>(), ds1.as<double>(), ds2.as<double>(), dt1.as<double>(), dt2.as<double>(), nullptr));
+        HIPCHK(hipMemcpy(xy_out, out.p, sizeof(double) * 2 * ni * nj, hipMemcpyDeviceToHost));
+        return TM_OK;
+    });
+}
+
+int tm_tfi_linear2d(double* xy_out, uint64_t ni, uint64_t nj, const double* e_i_min, const double* e_i_max, const double* e_j_min,
+                    const double* e_j_max) {
+    return guarded([&]() {
+        if (!xy_out || !e_i_min || !e_i_max || !e_j_min || !e_j_max) throw TmError(TM_E_ARG, "null argument");
+        if (ni < 2 || nj < 2 || ni * nj >= (uint64_t{1} << 31)) throw TmError(TM_E_SIZE, "InconsistentSize (tfi.zig:30)");
+        require_gfx950();
+        const size_t ei = sizeof(double) * 2 * ni, ej = sizeof(double) * 2 * nj;
+        DevBuf out(sizeof(double) * 2 * ni * nj), a(ei), b(ei), c(ej), d(ej);
+        HIPCHK(hipMemcpy(a.p, e_i_min, ei, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(b.p, e_i_max, ei, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(c.p, e_j_min, ej, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(d.p, e_j_max, ej, hipMemcpyHostToDevice));
+        HIPCHK(launch_tfi_linear2d(out.as<double2>(), static_cast<int>(ni), static_cast<int>(nj), a.as<double2>(), b.as<double2>(), c.as<double2>(),
+                                   d.as<double2>(), nullptr));
+        HIPCHK(hipMemcpy(xy_out, out.p, sizeof(double) * 2 * ni * nj, hipMemcpyDeviceToHost));
+        return TM_OK;
+    });
+}
+
+int tm_dev_tfi_block(double* d_xy, uint64_t ni, uint64_t nj, const double* a, const double* b, const double* c, const double* d,
+                     const double* s1, const double* s2, const double* t1, const double* t2, void* stream) {
+    return guarded([&]() {
+        if (ni < 2 || nj < 2 || ni * nj >= (uint64_t{1} << 31)) throw TmError(TM_E_SIZE, "InconsistentSize");
+        HIPCHK(launch_tfi_block(reinterpret_cast<double2*>(d_xy), static_cast<int>(ni), static_cast<int>(nj), reinterpret_cast<const double2*>(a),
+                                reinterpret_cast<const double2*>(b), reinterpret_cast<const double2*>(c), reinterpret_cast<const double2*>(d), s1, s2,
+                                t1, t2, static_cast<hipStream_t>(stream)));
+        return TM_OK;
+    });
+}
+
+uint64_t tm_dev_relax_partials_needed(uint64_t ni, uint64_t nj) {
+    if (ni < 3 || nj < 3) return 0;
+    return static_cast<uint64_t>(apply_block_nwg(static_cast<int>(ni), static_cast<int>(nj))) * MAX_PARTIALS;
+}
+
+int tm_dev_relax_sweep(const double* d_in, double* d_out, uint64_t ni, uint64_t nj, double omega, double* d_partials,
+                       uint64_t partials_capacity, uint64_t* nwg, void* stream) {
+    return guarded([&]() {
+        if (ni < 3 || nj < 3 || ni * nj >= (uint64_t{1} << 31)) throw TmError(TM_E_SIZE, "block must be at least 3 x 3");
+        if (d_in == d_out) throw TmError(TM_E_ARG, "a Jacobi sweep cannot run in place");
+        const uint64_t need = tm_dev_relax_partials_needed(ni, nj);
+        if (d_partials && partials_capacity < need) throw TmError(TM_E_ARG, "partials buffer too small");
+        ApplyBlock a;
+        a.in = reinterpret_cast<const double2*>(d_in);
+        a.xk = a.in;
+        a.pq = nullptr;
+        a.aux = nullptr;
+        a.out = reinterpret_cast<double2*>(d_out);
+        a.ni = static_cast<int>(ni);
+        a.nj = static_cast<int>(nj);
+        a.omega = omega;
+        a.partials = d_partials;
+        hipStream_t st = static_cast<hipStream_t>(stream);
+        HIPCHK(launch_apply_block(a, MODE_RELAX, d_partials ? DOT_DELTA : DOT_NONE, st));
+        HIPCHK(launch_copy_perimeter(a.in, a.out, a.ni, a.nj, st));
+        if (nwg) *nwg = need / MAX_PARTIALS;
+        return TM_OK;
+    });
+}
+
+// ------------------------------------------------------------------ handle
+int tm_smoother_create(const tm_mesh_desc* mesh, const tm_solver_opt* opt, const tm_control_fn* cf, const tm_comm_hooks* hooks, void* stream,
+                       tm_smoother** out) {
+    return guarded([&]() {
+        if (!out) throw TmError(TM_E_ARG, "null output handle");
+        *out = nullptr;
+        require_gfx950();
+        auto h = std::make_unique<tm_smoother>();
+        h->impl.create(mesh, opt, cf, hooks, stream, false);
+        *out = h.release();
+        return TM_OK;
+    });
+}
+int tm_smoother_workspace_bytes(const tm_mesh_desc* mesh, const tm_solver_opt* opt, const tm_control_fn* cf, const tm_comm_hooks* hooks,
+                                uint64_t* bytes) {
+    return guarded([&]() {
+        if (!bytes) throw TmError(TM_E_ARG, "null output");
+        tm_smoother tmp;
+        tmp.impl.create(mesh, opt, cf, hooks, nullptr, true);
+        *bytes = tmp.impl.arena.used() + 4096;
+        return TM_OK;
+    });
+}
+void tm_smoother_destroy(tm_smoother* s) {
+    if (!s) return;
+    if (s->impl.h_S) (void)hipHostFree(s->impl.h_S);
+    if (s->impl.h_red) (void)hipHostFree(s->impl.h_red);
+    for (hipEvent_t e : s->impl.ev_start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : s->impl.ev_stop) (void)hipEventDestroy(e);
+    delete s;
+}
+int tm_smoother_iterate(tm_smoother* s, uint64_t iterations, tm_stats* stats) {
+    return guarded([&]() {
+        if (!s) throw TmError(TM_E_ARG, "null handle");
+        tm_stats st;
+        s->impl.iterate(iterations, &st);
+        if (stats) *stats = st;
+        return st.not_converged ? TM_W_NOT_CONVERGED : TM_OK;
+    });
+}
+int tm_smoother_download(tm_smoother* s, const tm_mesh_desc* mesh) {
+    return guarded([&]() {
+        if (!s) throw TmError(TM_E_ARG, "null handle");
+        s->impl.download(mesh);
+        return TM_OK;
+    });
+}
+int tm_smoother_upload(tm_smoother* s, const tm_mesh_desc* mesh) {
+    return guarded([&]() {
+        if (!s) throw TmError(TM_E_ARG, "null handle");
+        s->impl.upload(mesh);
+        s->impl.outer_done = 0;
+        if (s->impl.white) {
+            HIPCHK(hipMemsetAsync(s->impl.PQ, 0, sizeof(double2) * s->impl.n_local, s->impl.stream));
+            s->impl.white_launch(0);
+            s->impl.sync();
+        }
+        return TM_OK;
+    });
+}
+int tm_smoother_exchange_plan(const tm_smoother* s, int32_t* npeers, const int32_t** peer_rank, const int64_t** send_offset,
+                              const int64_t** send_count, const int64_t** recv_offset, const int64_t** recv_count) {
+    return guarded([&]() {
+        if (!s || !npeers) throw TmError(TM_E_ARG, "null argument");
+        const LocalPlan& lp = s->impl.lp;
+        *npeers = static_cast<int32_t>(lp.peer_rank.size());
+        if (peer_rank) *peer_rank = lp.peer_rank.data();
+        if (send_offset) *send_offset = lp.send_off.data();
+        if (send_count) *send_count = lp.send_cnt.data();
+        if (recv_offset) *recv_offset = lp.recv_off.data();
+        if (recv_count) *recv_count = lp.recv_cnt.data();
+        return TM_OK;
+    });
+}
+int tm_smoother_apply(tm_smoother* s, const double* in_xy, double* out_xy, int scaled) {
+    return guarded([&]() {
+        if (!s || !in_xy || !out_xy) throw TmError(TM_E_ARG, "null argument");
+        s->impl.apply_host(in_xy, out_xy, scaled);
+        return TM_OK;
+    });
+}
+int tm_smoother_rhs(tm_smoother* s, double* rhs_xy) {
+    return guarded([&]() {
+        if (!s || !rhs_xy) throw TmError(TM_E_ARG, "null argument");
+        s->impl.rhs_host(rhs_xy);
+        return TM_OK;
+    });
+}
+int tm_smoother_row_kinds(const tm_smoother* s, int32_t* kinds) {
+    return guarded([&]() {
+        if (!s || !kinds) throw TmError(TM_E_ARG, "null argument");
+        for (int64_t i = 0; i < s->impl.topo.dof; ++i) kinds[i] = -1;
+        for (const PlanRow& r : s->impl.all_rows) kinds[r.gid] = r.kind;
+        return TM_OK;
+    });
+}
+uint64_t tm_smoother_dof(const tm_smoother* s) { return s ? static_cast<uint64_t>(s->impl.topo.dof) : 0; }
+int tm_smoother_control_function(tm_smoother* s, double* pq) {
+    return guarded([&]() {
+        if (!s || !pq) throw TmError(TM_E_ARG, "null argument");
+        s->impl.control_function_host(pq);
+        return TM_OK;
+    });
+}
+
+int tm_smoother_profile(tm_smoother* s, int enable) {
+    return guarded([&]() {
+        if (!s) throw TmError(TM_E_ARG, "null handle");
+        s->impl.profile = enable != 0;
+        s->impl.ev_used = 0;
+        return TM_OK;
+    });
+}
+int tm_smoother_profile_read(tm_smoother* s, double* k2_ms_total, uint64_t* k2_launches) {
+    return guarded([&]() {
+        if (!s) throw TmError(TM_E_ARG, "null handle");
+        s->impl.profile_read(k2_ms_total, k2_launches);
+        return TM_OK;
+    });
+}
+
+// ------------------------------------------------------------------ seam 1 (smooth.zig:74-80)
+int tm_smooth_mesh(const tm_mesh_desc* mesh, uint64_t iterations, const tm_solver_opt* opt, const tm_control_fn* cf, tm_stats* stats) {
+    tm_smoother* h = nullptr;
+    int rc = tm_smoother_create(mesh, opt, cf, nullptr, nullptr, &h);
+    if (rc < 0) return rc;
+    tm_stats st;
+    std::memset(&st, 0, sizeof(st));
+    rc = tm_smoother_iterate(h, iterations, &st);
+    if (rc >= 0 && iterations > 0) {   // iterations == 0 returns the mesh untouched (input.zig:28 default)
+        const int rd = tm_smoother_download(h, mesh);
+        if (rd < 0) rc = rd;
+    }
+    tm_smoother_destroy(h);
+    if (stats) *stats = st;
+    return rc;
+}
+
+// ------------------------------------------------------------------ host-only planning export
+int tm_plan_build(const tm_mesh_desc* mesh, tm_plan_rows* out) {
+    return guarded([&]() {
+        if (!mesh || !out) throw TmError(TM_E_ARG, "null argument");
+        std::memset(out, 0, sizeof(*out));
+        Topology t;
+        if (!mesh->blocks || mesh->nblocks == 0) throw TmError(TM_E_ARG, "mesh description without blocks");
+        for (uint64_t b = 0; b < mesh->nblocks; ++b) {
+            t.ni.push_back(static_cast<int64_t>(mesh->blocks[b].ni));
+            t.nj.push_back(static_cast<int64_t>(mesh->blocks[b].nj));
+        }
+        auto rng = [](const tm_range& r) {
+            return TopoRange{static_cast<int64_t>(r.block), r.side, static_cast<int64_t>(r.start), static_cast<int64_t>(r.end)};
+        };
+        for (uint64_t c = 0; c < mesh->nconns; ++c) {
+            TopoConn tc;
+            tc.r[0] = rng(mesh->conns[c].r[0]);
+            tc.r[1] = rng(mesh->conns[c].r[1]);
+            tc.periodic = mesh->conns[c].has_periodicity != 0;
+            tc.per[0] = mesh->conns[c].periodicity[0];
+            tc.per[1] = mesh->conns[c].periodicity[1];
+            t.conns.push_back(tc);
+        }
+        for (uint64_t c = 0; c < mesh->nbcs; ++c) t.bcs.push_back(TopoCond{rng(mesh->bcs[c].range), mesh->bcs[c].kind});
+        t.finalize();
+        const std::vector<PlanRow> rows = build_rows(t);
+        const size_t n = rows.size();
+        out->nrows = n;
+        out->row = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * (n ? n : 1)));
+        out->kind = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (n ? n : 1)));
+        out->ncols = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * (n ? n : 1)));
+        out->cols = static_cast<int64_t*>(std::malloc(sizeof(int64_t) * 9 * (n ? n : 1)));
+        out->coef_x = static_cast<double*>(std::malloc(sizeof(double) * 9 * (n ? n : 1)));
+        out->coef_y = static_cast<double*>(std::malloc(sizeof(double) * 9 * (n ? n : 1)));
+        out->rhs = static_cast<double*>(std::malloc(sizeof(double) * 2 * (n ? n : 1)));
+        out->slot = static_cast<int32_t*>(std::malloc(sizeof(int32_t) * 9 * (n ? n : 1)));
+        if (!out->row || !out->kind || !out->ncols || !out->cols || !out->coef_x || !out->coef_y || !out->rhs || !out->slot) {
+            tm_plan_free(out);
+            throw TmError(TM_E_MEMORY, "out of host memory");
+        }
+        const double nan = std::numeric_limits<double>::quiet_NaN();
+        for (size_t k = 0; k < n; ++k) {
+            const PlanRow& r = rows[k];
+            out->row[k] = r.gid;
+            out->kind[k] = r.kind;
+            out->ncols[k] = r.ncols;
+            for (int q = 0; q < 9; ++q) {
+                out->cols[k * 9 + q] = q < r.ncols ? r.col[q] : -1;
+                out->coef_x[k * 9 + q] = (r.kind == KIND_SMOOTHED) ? nan : r.cx[q];
+                out->coef_y[k * 9 + q] = (r.kind == KIND_SMOOTHED) ? nan : r.cy[q];
+                out->slot[k * 9 + q] = r.slot[q];
+            }
+            out->rhs[2 * k] = (r.rhs_coord & 1) ? nan : r.rhs[0];
+            out->rhs[2 * k + 1] = (r.rhs_coord & 2) ? nan : r.rhs[1];
+        }
+        return TM_OK;
+    });
+}
+void tm_plan_free(tm_plan_rows* rows) {
+    if (!rows) return;
+    std::free(rows->row);
+    std::free(rows->kind);
+    std::free(rows->ncols);
+    std::free(rows->cols);
+    std::free(rows->coef_x);
+    std::free(rows->coef_y);
+    std::free(rows->rhs);
+    std::free(rows->slot);
+    std::memset(rows, 0, sizeof(*rows));
+}
+
+}  // extern "C"

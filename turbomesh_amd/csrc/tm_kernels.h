@@ -1,0 +1,123 @@
+// Launch interface of the gfx950 kernels (internal to libtm_hip.so).
+// Kernel ids follow SURVEY.md section 7: K1 tfi_blend, K2 winslow_apply, K3 fused Krylov vector
+// kernels, K4/K5 perimeter rows, K6 white control function, K7 residual + copy-back.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace tmh {
+
+// ---- K2 modes: what is written for an interior row with sum = (A(xk) in)_row, dinv = 1/a_ii
+enum ApplyMode : int {
+    MODE_RAW = 0,      // out = sum
+    MODE_SCALED = 1,   // out = sum * dinv                      (D^-1 A in)
+    MODE_RESID = 2,    // out = rhs*dinv - sum*dinv             (D^-1 (b - A in)), rhs = 0 on interior rows
+    MODE_RELAX = 3     // out = in + omega * (rhs*dinv - sum*dinv)
+};
+// ---- fused partial reductions written per workgroup (x and y components separately)
+enum DotMode : int {
+    DOT_NONE = 0,
+    DOT_AUX = 1,    // [aux.out]_x, [aux.out]_y                       (sigma = r_hat . v)
+    DOT_IN = 2,     // [in.out]_x, [in.out]_y, [out.out]_x, [out.out]_y   (t.s, t.t)
+    DOT_OUT2 = 3,   // [out.out]_x, [out.out]_y                       (||r||^2)
+    DOT_DELTA = 4   // [(out-in)^2]_x, [(out-in)^2]_y                 (relax: sum dx^2, dy^2)
+};
+constexpr int MAX_PARTIALS = 4;
+
+struct ApplyBlock {
+    const double2* in;    // vector the operator acts on, pointing at the block's node (0,0)
+    const double2* xk;    // frozen coordinates the coefficients are built from (== in for field mode)
+    const double2* pq;    // control function (P,Q) or nullptr (Laplace)
+    const double2* aux;   // second vector for DOT_AUX or nullptr
+    double2* out;
+    int ni, nj;
+    double omega;
+    double* partials;     // [nwg * MAX_PARTIALS] for this launch
+};
+// number of workgroups k2 launches for a block (also the number of partial rows it writes)
+int apply_block_nwg(int ni, int nj);
+void tune_apply(int rows_per_chunk, int unroll);   // <=0 keeps the current value
+hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_t stream);
+
+// ---- K4/K5 perimeter rows (device SoA, built on the host by tm_plan)
+struct EdgeRowsDev {
+    int nrows = 0;
+    const int32_t* row = nullptr;       // [nrows] local vector index of the row
+    const int8_t* kind = nullptr;       // [nrows] BlockBoundaryPointKind
+    const int8_t* ncols = nullptr;      // [nrows]
+    const int32_t* cols = nullptr;      // [nrows*9] local vector indices, ascending GLOBAL id order
+    const double* cx = nullptr;         // [nrows*9] static x-system coefficients
+    const double* cy = nullptr;         // [nrows*9] static y-system coefficients
+    const int8_t* slot = nullptr;       // [nrows*9] smoothed rows: stencil slot per column
+    const int32_t* metric = nullptr;    // [nrows*4] smoothed rows: local ids of im1_j, ip1_j, i_jm1, i_jp1
+    const double* per = nullptr;        // [nrows*2] periodicity of the row's connection
+    const uint8_t* flags = nullptr;     // [nrows] bit0 periodic, bit1 swap (Q,P)
+    const double* rhs = nullptr;        // [nrows*2] static right-hand side
+    const int8_t* self = nullptr;       // [nrows] position of the diagonal entry within cols
+};
+constexpr int EDGE_BLOCK = 128;
+inline int edge_rows_nwg(int nrows) { return (nrows + EDGE_BLOCK - 1) / EDGE_BLOCK; }
+// out/in/xk/pq/aux are the rank-local vectors (owned rows then ghost rows)
+hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const double2* xk, const double2* pq, const double2* aux,
+                            double2* out, double omega, int mode, int dot, double* partials, hipStream_t stream);
+// b (unscaled) per perimeter row scattered into a dense vector that was zeroed by the caller; scaled!=0 writes D^-1 b
+hipError_t launch_edge_rhs(const EdgeRowsDev& e, const double2* xk, const double2* pq, double2* rhs_out, int scaled,
+                           double* partials /* [nwg*MAX_PARTIALS]: sum (D^-1 b)^2 x,y */, hipStream_t stream);
+
+// ---- reductions: sum partial rows [nwg][MAX_PARTIALS] in fixed order into red[MAX_PARTIALS]
+hipError_t launch_finalize(const double* partials, int nwg, double* red, hipStream_t stream);
+
+// ---- K3: fused BiCGStab vector kernels with device-resident scalars
+struct KrylovScalars {   // one per smoother, lives in device memory; index = component (0 x, 1 y)
+    double rho[2], rho_old[2], alpha[2], omega[2], beta[2];
+    double tol2[2];       // squared absolute tolerance on ||r||_2
+    double rr[2];         // last ||r||^2 (or ||s||^2 on early exit)
+    double rr0[2];        // ||r0||^2 of the current solve
+    int32_t done[2];      // 0 active, 1 converged, 2 breakdown
+    int32_t early[2];     // ||s|| <= tol in this iteration: omega := 0
+    int32_t iters;        // iterations executed in the current solve
+    int32_t _pad;
+};
+constexpr int VEC_BLOCK = 256;
+int vec_nwg(int64_t n);
+// step ids for launch_scalar_update: consume red[], update KrylovScalars
+enum ScalarStep : int { STEP_INIT = 0, STEP_SIGMA = 1, STEP_SS = 2, STEP_TSTT = 3, STEP_RHO = 4, STEP_TOL = 5 };
+// STEP_TOL: red[0..1] = ||D^-1 b||^2 -> tol2 = max(atol, rtol*||D^-1 b||)^2
+hipError_t launch_scalar_update(KrylovScalars* S, const double* red, int step, hipStream_t stream, double rtol = 0.0, double atol = 0.0);
+// p = r + beta (p - omega v)
+hipError_t launch_p_update(const KrylovScalars* S, const double2* r, double2* p, const double2* v, int64_t n, hipStream_t stream);
+// s = r - alpha v ; partials: ||s||^2 (x,y)
+hipError_t launch_s_update(const KrylovScalars* S, const double2* r, const double2* v, double2* s, int64_t n, double* partials,
+                           hipStream_t stream);
+// u += alpha p + omega s ; r = s - omega t ; partials: r_hat.r (x,y), r.r (x,y)
+hipError_t launch_xr_update(const KrylovScalars* S, double2* u, const double2* p, const double2* s, const double2* t, double2* r,
+                            const double2* r_hat, int64_t n, double* partials, hipStream_t stream);
+// K7: partials sum (xk-u)^2 (x,y); xk <- u
+hipError_t launch_residual_copyback(double2* xk, const double2* u, int64_t n, double* partials, hipStream_t stream);
+// gather rows for the halo exchange: dst[k] = src[ids[k]]
+hipError_t launch_gather_rows(const double2* src, const int32_t* ids, int64_t n, double2* dst, hipStream_t stream);
+
+// out perimeter <- in perimeter of one block (fixed boundary of the stand-alone relax sweep)
+hipError_t launch_copy_perimeter(const double2* in, double2* out, int ni, int nj, hipStream_t stream);
+
+// ---- K1 TFI
+hipError_t launch_tfi_block(double2* xy, int ni, int nj, const double2* x_i_min, const double2* x_i_max, const double2* x_j_min,
+                            const double2* x_j_max, const double* s1, const double* s2, const double* t1, const double* t2,
+                            hipStream_t stream);
+hipError_t launch_tfi_linear2d(double2* xy, int ni, int nj, const double2* e_i_min, const double2* e_i_max, const double2* e_j_min,
+                               const double2* e_j_max, hipStream_t stream);
+
+// ---- K6 white control function (wall_control_function.zig:70-473), blocks 0,1 + connection 0
+struct WhiteArgs {
+    const double2* x0;   // block 0 coordinates
+    const double2* x1;   // block 1 coordinates
+    double2* pq0;        // control function of block 0
+    double2* pq1;
+    int ni0, nj0, ni1, nj1;
+    // leading-edge node across connection 0 (RangeFillMatrixIterator of connection 0, first point)
+    int le_p0, le_p1, le_fi0, le_fi1, le_dir0;
+    double ds_target, theta_target;
+};
+hipError_t launch_white(const WhiteArgs& w, int update, hipStream_t stream);
+
+}  // namespace tmh

@@ -1,0 +1,859 @@
+// gfx950 (MI355X, CDNA4) kernels of the structured-grid smoother.  HIP only, wave64 only.
+//
+// All arithmetic is fp64 and HBM-bandwidth bound (about 2 flop/B): no MFMA.  The file is built
+// with -ffp-contract=off so every a*b+c is evaluated exactly like the reference's Zig code
+// (strict IEEE, no fused multiply-add); the operator and TFI kernels then reproduce the CPU
+// oracle bit for bit, only the reductions (tree order) differ.
+//
+// K2 design (the dominant kernel).  A workgroup is 4 waves side by side; wave w owns the 64
+// columns [j0, j0+64) of a 256-column strip and MARCHES down a chunk of rows, keeping a
+// 3-row window of the vector (and of the frozen coordinate field) in registers:
+//   - every row is read once per wave with one coalesced 16 B/lane load (1 KiB per wave,
+//     128 B-line aligned because strips start at multiples of 64 columns);
+//   - the j-1 / j+1 neighbours come from the adjacent lanes by DPP wave shifts
+//     (v_mov_b32_dpp wave_shr:1 / wave_shl:1), the two strip-edge columns from one extra
+//     2-lane load whose cache line is the neighbouring wave's own line (L1/L2 hit);
+//   - no LDS tile, no barrier in the row loop, so the four waves stay independent and the
+//     loads of U rows are in flight together;
+//   - Jacobi scaling, the relaxation update and the partial dot products are fused into the
+//     same pass, so one sweep moves the compulsory 32 B/node (field mode, Laplace).
+// Workgroup ids are remapped so that every XCD (own L2) walks a contiguous range of
+// (row-chunk, strip) tiles: the halo lines shared by neighbouring tiles hit in that L2.
+#include "tm_kernels.h"
+
+namespace tmh {
+
+// ------------------------------------------------------------------------------------------
+// lane exchange: value of the previous / next lane of the wave; lane 0 / 63 keep `edge`
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double lane_prev(double edge, double v) {
+    int2 o = __builtin_bit_cast(int2, edge), s = __builtin_bit_cast(int2, v), r;
+    r.x = __builtin_amdgcn_update_dpp(o.x, s.x, 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
+    r.y = __builtin_amdgcn_update_dpp(o.y, s.y, 0x138, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, r);
+}
+__device__ __forceinline__ double lane_next(double edge, double v) {
+    int2 o = __builtin_bit_cast(int2, edge), s = __builtin_bit_cast(int2, v), r;
+    r.x = __builtin_amdgcn_update_dpp(o.x, s.x, 0x130 /* wave_shl:1 */, 0xf, 0xf, false);
+    r.y = __builtin_amdgcn_update_dpp(o.y, s.y, 0x130, 0xf, 0xf, false);
+    return __builtin_bit_cast(double, r);
+}
+__device__ __forceinline__ double2 lane_prev(double2 edge, double2 v) { return make_double2(lane_prev(edge.x, v.x), lane_prev(edge.y, v.y)); }
+__device__ __forceinline__ double2 lane_next(double2 edge, double2 v) { return make_double2(lane_next(edge.x, v.x), lane_next(edge.y, v.y)); }
+
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;   // valid in lane 0
+}
+
+// Per-workgroup partials: every lane holds acc[]; sums waves in fixed order -> deterministic.
+template <int NT>
+__device__ __forceinline__ void block_partials(double (&acc)[MAX_PARTIALS], double* dst) {
+    constexpr int NW = NT / 64;
+    __shared__ double sh[NW][MAX_PARTIALS];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < MAX_PARTIALS; ++k) {
+        const double s = wave_sum(acc[k]);
+        if (lane == 0) sh[wave][k] = s;
+    }
+    __syncthreads();
+    if (threadIdx.x < MAX_PARTIALS) {
+        double s = 0.0;
+#pragma unroll
+        for (int w = 0; w < NW; ++w) s += sh[w][threadIdx.x];
+        dst[threadIdx.x] = s;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// 9-point Winslow/Poisson coefficients -- reference smooth.zig:171-216 (StencilData.init),
+// same expression order.  Slots follow StencilData.index.
+// ------------------------------------------------------------------------------------------
+enum { S_I_J = 0, S_IP1_J, S_IM1_J, S_I_JP1, S_I_JM1, S_IP1_JP1, S_IP1_JM1, S_IM1_JP1, S_IM1_JM1 };
+
+template <bool HAS_PQ>
+__device__ __forceinline__ void stencil_coefs(double2 im1_j, double2 ip1_j, double2 i_jm1, double2 i_jp1, double P, double Q,
+                                              double (&c)[9]) {
+    const double x_xi = 0.5 * (ip1_j.x - im1_j.x);
+    const double x_eta = 0.5 * (i_jp1.x - i_jm1.x);
+    const double y_xi = 0.5 * (ip1_j.y - im1_j.y);
+    const double y_eta = 0.5 * (i_jp1.y - i_jm1.y);
+    const double g22 = x_eta * x_eta + y_eta * y_eta;
+    const double g12 = x_xi * x_eta + y_xi * y_eta;
+    const double g11 = x_xi * x_xi + y_xi * y_xi;
+    c[S_I_J] = -2.0 * g22 - 2.0 * g11;
+    if (HAS_PQ) {
+        c[S_IP1_J] = g22 * (1 + 0.5 * P);
+        c[S_IM1_J] = g22 * (1 - 0.5 * P);
+        c[S_I_JP1] = g11 * (1 + 0.5 * Q);
+        c[S_I_JM1] = g11 * (1 - 0.5 * Q);
+    } else {   // P = Q = 0: g * (1 +- 0) == g exactly
+        c[S_IP1_J] = g22;
+        c[S_IM1_J] = g22;
+        c[S_I_JP1] = g11;
+        c[S_I_JM1] = g11;
+    }
+    c[S_IP1_JP1] = -0.5 * g12;
+    c[S_IP1_JM1] = 0.5 * g12;
+    c[S_IM1_JP1] = 0.5 * g12;
+    c[S_IM1_JM1] = -0.5 * g12;
+}
+
+// out value for one row given sum=(A in)_row, the row's rhs and diagonal (both components)
+template <int MODE>
+__device__ __forceinline__ double row_out(double sum, double rhs, double diag, double in_self, double omega) {
+    if (MODE == MODE_RAW) return sum;
+    const double dinv = (diag == 0.0) ? 1.0 : 1.0 / diag;   // BiCGStab.zig:169-173
+    if (MODE == MODE_SCALED) return sum * dinv;
+    const double res = rhs * dinv - sum * dinv;
+    if (MODE == MODE_RESID) return res;
+    return in_self + omega * res;
+}
+
+template <int DOT>
+__device__ __forceinline__ void accumulate(double (&acc)[MAX_PARTIALS], double2 in_self, double2 out, double2 aux) {
+    if (DOT == DOT_AUX) {
+        acc[0] += aux.x * out.x;
+        acc[1] += aux.y * out.y;
+    } else if (DOT == DOT_IN) {
+        acc[0] += in_self.x * out.x;
+        acc[1] += in_self.y * out.y;
+        acc[2] += out.x * out.x;
+        acc[3] += out.y * out.y;
+    } else if (DOT == DOT_OUT2) {
+        acc[0] += out.x * out.x;
+        acc[1] += out.y * out.y;
+    } else if (DOT == DOT_DELTA) {
+        const double dx = out.x - in_self.x, dy = out.y - in_self.y;
+        acc[0] += dx * dx;
+        acc[1] += dy * dy;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2  winslow_apply: interior rows of one block (replaces smooth.zig:923-992 fill +
+//     BiCGStab.zig:424-435 mat-vec; row sum in the CSR column order of smooth.zig:494-502)
+// ------------------------------------------------------------------------------------------
+static int g_rows_per_chunk = 64;   // tunable (tm_tune)
+static int g_unroll = 4;
+
+template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U>
+__global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, int nRC) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    // XCD-aware tile order: physical workgroup b runs on XCD b%8; give each XCD a contiguous
+    // range of logical tiles (speed only, any placement is correct).
+    const int total = nSG * nRC;
+    const int bid = blockIdx.x;
+    const int q = total >> 3, rem = total & 7, xcd = bid & 7, k = bid >> 3;
+    const int logical = (xcd < rem) ? xcd * (q + 1) + k : rem * (q + 1) + (xcd - rem) * q + k;
+    const int rc = logical / nSG;
+    const int sg = logical - rc * nSG;
+
+    const int ni = a.ni, nj = a.nj;
+    const int j0 = (sg * 4 + wave) * 64;
+    const int j = j0 + lane;
+    const int jc = min(j, nj - 1);
+    const bool edge_lane = (lane == 0) || (lane == 63);
+    const int hcol = (lane == 0) ? max(j0 - 1, 0) : min(j0 + 64, nj - 1);
+    const bool valid_col = (j >= 1) && (j <= nj - 2);
+    const int i0 = 1 + rc * RI;
+    const int i1 = min(i0 + RI, ni - 1);   // output rows [i0, i1)
+
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+
+    if (j0 < nj && i0 < i1) {   // wave-uniform
+        auto load_row = [&](const double2* __restrict__ v, int row, double2& c, double2& h) {
+            const double2* rp = v + static_cast<size_t>(row) * nj;
+            c = rp[jc];
+            h = c;
+            if (edge_lane) h = rp[hcol];
+        };
+        // 3-row window of the vector: m = row i-1, c = row i, p = row i+1; l/r = columns j-1/j+1
+        double2 wm_c, wm_h, wc_c, wc_h;
+        load_row(a.in, i0 - 1, wm_c, wm_h);
+        load_row(a.in, i0, wc_c, wc_h);
+        double2 wm_l = lane_prev(wm_h, wm_c), wm_r = lane_next(wm_h, wm_c);
+        double2 wc_l = lane_prev(wc_h, wc_c), wc_r = lane_next(wc_h, wc_c);
+        // frozen coordinates when they are a different array: centre of rows i-1, i+1; l/r of row i
+        double2 xm_c = wm_c, xc_c = wc_c, xc_l = wc_l, xc_r = wc_r;
+        if (!FIELD) {
+            double2 t_h;
+            load_row(a.xk, i0 - 1, xm_c, t_h);
+            load_row(a.xk, i0, xc_c, t_h);
+            xc_l = lane_prev(t_h, xc_c);
+            xc_r = lane_next(t_h, xc_c);
+        }
+
+        for (int ib = i0; ib < i1; ib += U) {
+            double2 pc[U], ph[U], xpc[U], xph[U], pqv[U], auxv[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {   // issue all loads of the group first
+                const int prow = min(ib + u + 1, ni - 1);
+                load_row(a.in, prow, pc[u], ph[u]);
+                if (!FIELD) load_row(a.xk, prow, xpc[u], xph[u]);
+                const size_t cur = static_cast<size_t>(min(ib + u, ni - 2)) * nj + jc;
+                if (HAS_PQ) pqv[u] = a.pq[cur];
+                if (DOT == DOT_AUX) auxv[u] = a.aux[cur];
+            }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                const int row = ib + u;
+                const double2 wp_c = pc[u];
+                const double2 wp_l = lane_prev(ph[u], pc[u]), wp_r = lane_next(ph[u], pc[u]);
+
+                double c[9];
+                const double P = HAS_PQ ? pqv[u].x : 0.0, Q = HAS_PQ ? pqv[u].y : 0.0;
+                if (FIELD) stencil_coefs<HAS_PQ>(wm_c, wp_c, wc_l, wc_r, P, Q, c);
+                else stencil_coefs<HAS_PQ>(xm_c, xpc[u], xc_l, xc_r, P, Q, c);
+
+                double sx = 0.0, sy = 0.0;   // CSR order: (i-1,j-1) (i-1,j) (i-1,j+1) (i,j-1) (i,j) (i,j+1) (i+1,j-1) (i+1,j) (i+1,j+1)
+                sx += c[S_IM1_JM1] * wm_l.x; sy += c[S_IM1_JM1] * wm_l.y;
+                sx += c[S_IM1_J] * wm_c.x;   sy += c[S_IM1_J] * wm_c.y;
+                sx += c[S_IM1_JP1] * wm_r.x; sy += c[S_IM1_JP1] * wm_r.y;
+                sx += c[S_I_JM1] * wc_l.x;   sy += c[S_I_JM1] * wc_l.y;
+                sx += c[S_I_J] * wc_c.x;     sy += c[S_I_J] * wc_c.y;
+                sx += c[S_I_JP1] * wc_r.x;   sy += c[S_I_JP1] * wc_r.y;
+                sx += c[S_IP1_JM1] * wp_l.x; sy += c[S_IP1_JM1] * wp_l.y;
+                sx += c[S_IP1_J] * wp_c.x;   sy += c[S_IP1_J] * wp_c.y;
+                sx += c[S_IP1_JP1] * wp_r.x; sy += c[S_IP1_JP1] * wp_r.y;
+
+                double2 o;
+                o.x = row_out<MODE>(sx, 0.0, c[S_I_J], wc_c.x, a.omega);
+                o.y = row_out<MODE>(sy, 0.0, c[S_I_J], wc_c.y, a.omega);
+                if (row < i1 && valid_col) {
+                    a.out[static_cast<size_t>(row) * nj + j] = o;
+                    accumulate<DOT>(acc, wc_c, o, (DOT == DOT_AUX) ? auxv[u] : o);
+                }
+                // slide the window down one row
+                wm_c = wc_c; wm_l = wc_l; wm_r = wc_r;
+                wc_c = wp_c; wc_l = wp_l; wc_r = wp_r;
+                if (!FIELD) {
+                    xm_c = xc_c;
+                    xc_c = xpc[u];
+                    xc_l = lane_prev(xph[u], xpc[u]);
+                    xc_r = lane_next(xph[u], xpc[u]);
+                }
+            }
+        }
+    }
+    if (DOT != DOT_NONE) block_partials<256>(acc, a.partials + static_cast<size_t>(bid) * MAX_PARTIALS);
+}
+
+static inline int rows_per_chunk(int ni) {
+    const int interior = ni - 2;
+    int RI = g_rows_per_chunk;
+    if (RI > interior) RI = interior;
+    if (RI < 1) RI = 1;
+    return RI;
+}
+int apply_block_nwg(int ni, int nj) {
+    const int RI = rows_per_chunk(ni);
+    const int nSG = (nj + 255) / 256;
+    const int nRC = (ni - 2 + RI - 1) / RI;
+    return nSG * nRC;
+}
+
+template <int MODE, int DOT, bool FIELD, bool HAS_PQ>
+static hipError_t launch_apply_u(const ApplyBlock& a, int RI, int nSG, int nRC, hipStream_t st) {
+    const dim3 grid(nSG * nRC), block(256);
+    switch (g_unroll) {
+        case 1: hipLaunchKernelGGL((k_apply<MODE, DOT, FIELD, HAS_PQ, 1>), grid, block, 0, st, a, RI, nSG, nRC); break;
+        case 2: hipLaunchKernelGGL((k_apply<MODE, DOT, FIELD, HAS_PQ, 2>), grid, block, 0, st, a, RI, nSG, nRC); break;
+        default: hipLaunchKernelGGL((k_apply<MODE, DOT, FIELD, HAS_PQ, 4>), grid, block, 0, st, a, RI, nSG, nRC); break;
+    }
+    return hipGetLastError();
+}
+template <int MODE, int DOT>
+static hipError_t launch_apply_md(const ApplyBlock& a, int RI, int nSG, int nRC, hipStream_t st) {
+    const bool field = (a.in == a.xk);
+    const bool pq = a.pq != nullptr;
+    if (field && pq) return launch_apply_u<MODE, DOT, true, true>(a, RI, nSG, nRC, st);
+    if (field) return launch_apply_u<MODE, DOT, true, false>(a, RI, nSG, nRC, st);
+    if (pq) return launch_apply_u<MODE, DOT, false, true>(a, RI, nSG, nRC, st);
+    return launch_apply_u<MODE, DOT, false, false>(a, RI, nSG, nRC, st);
+}
+
+hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_t st) {
+    if (a.ni < 3 || a.nj < 3) return hipSuccess;   // no interior rows
+    const int RI = rows_per_chunk(a.ni);
+    const int nSG = (a.nj + 255) / 256;
+    const int nRC = (a.ni - 2 + RI - 1) / RI;
+    // the (mode, dot) pairs the smoother uses
+    if (mode == MODE_RAW && dot == DOT_NONE) return launch_apply_md<MODE_RAW, DOT_NONE>(a, RI, nSG, nRC, st);
+    if (mode == MODE_SCALED && dot == DOT_NONE) return launch_apply_md<MODE_SCALED, DOT_NONE>(a, RI, nSG, nRC, st);
+    if (mode == MODE_SCALED && dot == DOT_AUX) return launch_apply_md<MODE_SCALED, DOT_AUX>(a, RI, nSG, nRC, st);
+    if (mode == MODE_SCALED && dot == DOT_IN) return launch_apply_md<MODE_SCALED, DOT_IN>(a, RI, nSG, nRC, st);
+    if (mode == MODE_RESID && dot == DOT_OUT2) return launch_apply_md<MODE_RESID, DOT_OUT2>(a, RI, nSG, nRC, st);
+    if (mode == MODE_RESID && dot == DOT_NONE) return launch_apply_md<MODE_RESID, DOT_NONE>(a, RI, nSG, nRC, st);
+    if (mode == MODE_RELAX && dot == DOT_DELTA) return launch_apply_md<MODE_RELAX, DOT_DELTA>(a, RI, nSG, nRC, st);
+    if (mode == MODE_RELAX && dot == DOT_NONE) return launch_apply_md<MODE_RELAX, DOT_NONE>(a, RI, nSG, nRC, st);
+    return hipErrorInvalidValue;
+}
+
+void tune_apply(int rows, int unroll) {
+    if (rows > 0) g_rows_per_chunk = rows;
+    if (unroll == 1 || unroll == 2 || unroll == 4) g_unroll = unroll;
+}
+
+// ------------------------------------------------------------------------------------------
+// K4/K5 perimeter rows: fixed / connected / junction / sliding rows (static coefficients,
+// smooth.zig:780-921, 1115-1165) and `smoothed` interface rows (cross-block 9-point stencil,
+// smooth.zig:994-1105).  One thread per row; columns are visited in ascending global id
+// (the reference's CSR order) so the row sum matches the CPU mat-vec bit for bit.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double pick9(const double (&c)[9], int s) {
+    double v = c[0];
+#pragma unroll
+    for (int k = 1; k < 9; ++k) v = (s == k) ? c[k] : v;
+    return v;
+}
+
+template <int MODE, int DOT>
+__global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const double2* __restrict__ in,
+                                                          const double2* __restrict__ xk, const double2* __restrict__ pq,
+                                                          const double2* __restrict__ aux, double2* __restrict__ out, double omega,
+                                                          double* partials) {
+    const int r = blockIdx.x * EDGE_BLOCK + threadIdx.x;
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    if (r < e.nrows) {
+        const int row = e.row[r];
+        const int kind = e.kind[r];
+        const int nc = e.ncols[r];
+        const int self = e.self[r];
+        double sx = 0.0, sy = 0.0, rhs_x, rhs_y, diag_x, diag_y;
+        if (kind == 1 /* smoothed */) {
+            const int32_t* m = e.metric + static_cast<size_t>(r) * 4;
+            const double2 im1_j = xk[m[0]], ip1_j = xk[m[1]], i_jm1 = xk[m[2]];
+            double2 i_jp1 = xk[m[3]];
+            const bool periodic = e.flags[r] & 1;
+            const double per_x = e.per[2 * r], per_y = e.per[2 * r + 1];
+            if (periodic) {   // types.add(p, types.neg(periodicity)), smooth.zig:1032
+                i_jp1.x = i_jp1.x + (-per_x);
+                i_jp1.y = i_jp1.y + (-per_y);
+            }
+            const double2 cf = pq ? pq[row] : make_double2(0.0, 0.0);
+            // periodic rows pass (P,Q), non-periodic rows pass (Q,P): smooth.zig:1040-1041 vs 1082-1083
+            const double P = periodic ? cf.x : cf.y, Q = periodic ? cf.y : cf.x;
+            double c[9];
+            stencil_coefs<true>(im1_j, ip1_j, i_jm1, i_jp1, P, Q, c);
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                const double ck = pick9(c, e.slot[static_cast<size_t>(r) * 9 + k]);
+                const double2 w = in[e.cols[static_cast<size_t>(r) * 9 + k]];
+                sx += ck * w.x;
+                sy += ck * w.y;
+            }
+            diag_x = diag_y = c[S_I_J];
+            if (periodic) {   // smooth.zig:1060-1061
+                const double cs = c[S_IM1_JP1] + c[S_I_JP1] + c[S_IP1_JP1];
+                rhs_x = per_x * cs;
+                rhs_y = per_y * cs;
+            } else {
+                rhs_x = 0.0;
+                rhs_y = 0.0;
+            }
+        } else {
+            diag_x = 0.0;
+            diag_y = 0.0;
+#pragma unroll
+            for (int k = 0; k < 9; ++k) {
+                if (k < nc) {
+                    const double ax = e.cx[static_cast<size_t>(r) * 9 + k], ay = e.cy[static_cast<size_t>(r) * 9 + k];
+                    const double2 w = in[e.cols[static_cast<size_t>(r) * 9 + k]];
+                    sx += ax * w.x;
+                    sy += ay * w.y;
+                    if (k == self) {
+                        diag_x = ax;
+                        diag_y = ay;
+                    }
+                }
+            }
+            rhs_x = e.rhs[2 * r];
+            rhs_y = e.rhs[2 * r + 1];
+        }
+        const double2 w_self = in[row];
+        // constraint rows are enforced exactly in a relaxation sweep (omega = 1); smoothed rows relax like interior rows
+        const double om = (kind == 1) ? omega : 1.0;
+        double2 o;
+        o.x = row_out<MODE>(sx, rhs_x, diag_x, w_self.x, om);
+        o.y = row_out<MODE>(sy, rhs_y, diag_y, w_self.y, om);
+        out[row] = o;
+        accumulate<DOT>(acc, w_self, o, (DOT == DOT_AUX) ? aux[row] : o);
+    }
+    if (DOT != DOT_NONE) block_partials<EDGE_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
+}
+
+hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const double2* xk, const double2* pq, const double2* aux,
+                            double2* out, double omega, int mode, int dot, double* partials, hipStream_t st) {
+    if (e.nrows == 0) return hipSuccess;
+    const dim3 grid(edge_rows_nwg(e.nrows)), block(EDGE_BLOCK);
+#define TM_EDGE(M, D)                                                                                                  \
+    if (mode == M && dot == D) {                                                                                       \
+        hipLaunchKernelGGL((k_edge_rows<M, D>), grid, block, 0, st, e, in, xk, pq, aux, out, omega, partials);         \
+        return hipGetLastError();                                                                                      \
+    }
+    TM_EDGE(MODE_RAW, DOT_NONE)
+    TM_EDGE(MODE_SCALED, DOT_NONE)
+    TM_EDGE(MODE_SCALED, DOT_AUX)
+    TM_EDGE(MODE_SCALED, DOT_IN)
+    TM_EDGE(MODE_RESID, DOT_OUT2)
+    TM_EDGE(MODE_RESID, DOT_NONE)
+    TM_EDGE(MODE_RELAX, DOT_DELTA)
+    TM_EDGE(MODE_RELAX, DOT_NONE)
+#undef TM_EDGE
+    return hipErrorInvalidValue;
+}
+
+// right-hand side of the perimeter rows (interior rows have b = 0)
+__global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rhs(EdgeRowsDev e, const double2* __restrict__ xk, const double2* __restrict__ pq,
+                                                         double2* __restrict__ rhs_out, int scaled, double* partials) {
+    const int r = blockIdx.x * EDGE_BLOCK + threadIdx.x;
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    if (r < e.nrows) {
+        const int row = e.row[r];
+        const int kind = e.kind[r];
+        double rhs_x, rhs_y, diag_x, diag_y;
+        if (kind == 1) {
+            const int32_t* m = e.metric + static_cast<size_t>(r) * 4;
+            const double2 im1_j = xk[m[0]], ip1_j = xk[m[1]], i_jm1 = xk[m[2]];
+            double2 i_jp1 = xk[m[3]];
+            const bool periodic = e.flags[r] & 1;
+            const double per_x = e.per[2 * r], per_y = e.per[2 * r + 1];
+            if (periodic) {
+                i_jp1.x = i_jp1.x + (-per_x);
+                i_jp1.y = i_jp1.y + (-per_y);
+            }
+            const double2 cf = pq ? pq[row] : make_double2(0.0, 0.0);
+            const double P = periodic ? cf.x : cf.y, Q = periodic ? cf.y : cf.x;
+            double c[9];
+            stencil_coefs<true>(im1_j, ip1_j, i_jm1, i_jp1, P, Q, c);
+            diag_x = diag_y = c[S_I_J];
+            const double cs = c[S_IM1_JP1] + c[S_I_JP1] + c[S_IP1_JP1];
+            rhs_x = periodic ? per_x * cs : 0.0;
+            rhs_y = periodic ? per_y * cs : 0.0;
+        } else {
+            const int self = e.self[r];
+            diag_x = e.cx[static_cast<size_t>(r) * 9 + self];
+            diag_y = e.cy[static_cast<size_t>(r) * 9 + self];
+            rhs_x = e.rhs[2 * r];
+            rhs_y = e.rhs[2 * r + 1];
+        }
+        const double bx = rhs_x * ((diag_x == 0.0) ? 1.0 : 1.0 / diag_x);
+        const double by = rhs_y * ((diag_y == 0.0) ? 1.0 : 1.0 / diag_y);
+        if (rhs_out) rhs_out[row] = scaled ? make_double2(bx, by) : make_double2(rhs_x, rhs_y);
+        acc[0] = bx * bx;
+        acc[1] = by * by;
+    }
+    if (partials) block_partials<EDGE_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
+}
+hipError_t launch_edge_rhs(const EdgeRowsDev& e, const double2* xk, const double2* pq, double2* rhs_out, int scaled, double* partials,
+                           hipStream_t st) {
+    if (e.nrows == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_edge_rhs, dim3(edge_rows_nwg(e.nrows)), dim3(EDGE_BLOCK), 0, st, e, xk, pq, rhs_out, scaled, partials);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// reductions
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partials, int nwg, double* __restrict__ red) {
+    __shared__ double sh[256][MAX_PARTIALS];
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < nwg; i += 256) {
+#pragma unroll
+        for (int k = 0; k < MAX_PARTIALS; ++k) acc[k] += partials[static_cast<size_t>(i) * MAX_PARTIALS + k];
+    }
+#pragma unroll
+    for (int k = 0; k < MAX_PARTIALS; ++k) sh[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (threadIdx.x < off) {
+#pragma unroll
+            for (int k = 0; k < MAX_PARTIALS; ++k) sh[threadIdx.x][k] += sh[threadIdx.x + off][k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < MAX_PARTIALS) red[threadIdx.x] = sh[0][threadIdx.x];
+}
+hipError_t launch_finalize(const double* partials, int nwg, double* red, hipStream_t st) {
+    hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, partials, nwg, red);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// K3 fused BiCGStab vector kernels (recurrences of BiCGStab.zig:279-370 on D^-1 A, no
+// preconditioner vector: the Jacobi scaling lives in K2).  Scalars stay on the device.
+// ------------------------------------------------------------------------------------------
+int vec_nwg(int64_t n) {
+    int64_t g = (n + VEC_BLOCK - 1) / VEC_BLOCK;
+    const int64_t cap = 256 * 8;   // 8 workgroups per CU, grid-stride beyond
+    if (g > cap) g = cap;
+    if (g < 1) g = 1;
+    return static_cast<int>(g);
+}
+
+__global__ void k_scalar_update(KrylovScalars* S, const double* __restrict__ red, int step, double rtol, double atol) {
+    const int c = threadIdx.x;
+    if (c >= 2) return;
+    const double tiny = 1e-290;
+    if (step == STEP_TOL) {
+        const double tol = fmax(atol, rtol * sqrt(red[c]));
+        S->tol2[c] = tol * tol;
+        return;
+    }
+    if (step == STEP_INIT) {   // red[0..1] = ||r0||^2 ; r_hat = r0 so rho = ||r0||^2
+        const double rr = red[c];
+        S->rr[c] = rr;
+        S->rr0[c] = rr;
+        S->rho[c] = rr;
+        S->rho_old[c] = 1.0;
+        S->alpha[c] = 1.0;
+        S->omega[c] = 1.0;
+        S->beta[c] = rr;   // (rho/rho_old) * (alpha/omega); p = v = 0 so p <- r anyway
+        S->early[c] = 0;
+        const bool done = !(rr > S->tol2[c]);
+        S->done[c] = done ? 1 : 0;
+        if (done) S->alpha[c] = S->omega[c] = S->beta[c] = 0.0;
+        if (c == 0) S->iters = 0;
+        return;
+    }
+    if (S->done[c]) return;
+    if (step == STEP_SIGMA) {   // red = r_hat . v
+        const double sigma = red[c];
+        if (!(fabs(sigma) > tiny)) {
+            S->done[c] = 2;
+            S->alpha[c] = S->omega[c] = S->beta[c] = 0.0;
+        } else {
+            S->alpha[c] = S->rho[c] / sigma;
+        }
+    } else if (step == STEP_SS) {   // red = ||s||^2
+        S->rr[c] = red[c];
+        S->early[c] = (red[c] <= S->tol2[c]) ? 1 : 0;
+    } else if (step == STEP_TSTT) {   // red[0..1] = t.s, red[2..3] = t.t
+        const double ts = red[c], tt = red[2 + c];
+        if (S->early[c]) S->omega[c] = 0.0;
+        else if (!(tt > tiny)) {
+            S->omega[c] = 0.0;
+            S->early[c] = 2;   // breakdown after this update
+        } else S->omega[c] = ts / tt;
+    } else if (step == STEP_RHO) {   // red[0..1] = r_hat . r, red[2..3] = ||r||^2
+        const double rho_new = red[c], rr = red[2 + c];
+        S->rho_old[c] = S->rho[c];
+        S->rho[c] = rho_new;
+        S->rr[c] = rr;
+        int done = 0;
+        if (S->early[c] == 1 || rr <= S->tol2[c]) done = 1;
+        else if (S->early[c] == 2 || !(fabs(rho_new) > tiny) || !(fabs(S->omega[c]) > tiny)) done = 2;
+        S->early[c] = 0;
+        if (done) {
+            S->done[c] = done;
+            S->alpha[c] = S->omega[c] = S->beta[c] = 0.0;
+        } else {
+            S->beta[c] = (rho_new / S->rho_old[c]) * (S->alpha[c] / S->omega[c]);
+        }
+        if (c == 0) S->iters += 1;
+    }
+}
+hipError_t launch_scalar_update(KrylovScalars* S, const double* red, int step, hipStream_t st, double rtol, double atol) {
+    hipLaunchKernelGGL(k_scalar_update, dim3(1), dim3(64), 0, st, S, red, step, rtol, atol);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(VEC_BLOCK) void k_p_update(const KrylovScalars* __restrict__ S, const double2* __restrict__ r,
+                                                        double2* __restrict__ p, const double2* __restrict__ v, int64_t n) {
+    const double bx = S->beta[0], by = S->beta[1], ox = S->omega[0], oy = S->omega[1];
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * VEC_BLOCK) {
+        const double2 ri = r[i], pi = p[i], vi = v[i];
+        p[i] = make_double2(ri.x + bx * (pi.x - ox * vi.x), ri.y + by * (pi.y - oy * vi.y));   // BiCGStab.zig:310-312
+    }
+}
+hipError_t launch_p_update(const KrylovScalars* S, const double2* r, double2* p, const double2* v, int64_t n, hipStream_t st) {
+    hipLaunchKernelGGL(k_p_update, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, S, r, p, v, n);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(VEC_BLOCK) void k_s_update(const KrylovScalars* __restrict__ S, const double2* __restrict__ r,
+                                                        const double2* __restrict__ v, double2* __restrict__ s, int64_t n,
+                                                        double* partials) {
+    const double ax = S->alpha[0], ay = S->alpha[1];
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * VEC_BLOCK) {
+        const double2 ri = r[i], vi = v[i];
+        const double2 si = make_double2(ri.x - ax * vi.x, ri.y - ay * vi.y);   // BiCGStab.zig:325-327
+        s[i] = si;
+        acc[0] += si.x * si.x;
+        acc[1] += si.y * si.y;
+    }
+    block_partials<VEC_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
+}
+hipError_t launch_s_update(const KrylovScalars* S, const double2* r, const double2* v, double2* s, int64_t n, double* partials,
+                           hipStream_t st) {
+    hipLaunchKernelGGL(k_s_update, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, S, r, v, s, n, partials);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(VEC_BLOCK) void k_xr_update(const KrylovScalars* __restrict__ S, double2* __restrict__ u,
+                                                         const double2* __restrict__ p, const double2* __restrict__ s,
+                                                         const double2* __restrict__ t, double2* __restrict__ r,
+                                                         const double2* __restrict__ r_hat, int64_t n, double* partials) {
+    const double ax = S->alpha[0], ay = S->alpha[1], ox = S->omega[0], oy = S->omega[1];
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * VEC_BLOCK) {
+        const double2 pi = p[i], si = s[i], ti = t[i], rh = r_hat[i];
+        double2 ui = u[i];
+        ui.x += ax * pi.x;   // BiCGStab.zig:329-331
+        ui.y += ay * pi.y;
+        ui.x += ox * si.x;   // BiCGStab.zig:352-354
+        ui.y += oy * si.y;
+        u[i] = ui;
+        const double2 ri = make_double2(si.x - ox * ti.x, si.y - oy * ti.y);   // BiCGStab.zig:356-358
+        r[i] = ri;
+        acc[0] += rh.x * ri.x;
+        acc[1] += rh.y * ri.y;
+        acc[2] += ri.x * ri.x;
+        acc[3] += ri.y * ri.y;
+    }
+    block_partials<VEC_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
+}
+hipError_t launch_xr_update(const KrylovScalars* S, double2* u, const double2* p, const double2* s, const double2* t, double2* r,
+                            const double2* r_hat, int64_t n, double* partials, hipStream_t st) {
+    hipLaunchKernelGGL(k_xr_update, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, S, u, p, s, t, r, r_hat, n, partials);
+    return hipGetLastError();
+}
+
+// K7 residual + copy-back (smooth.zig:112-153): sum (x_old - x_new)^2 per component, then the
+// frozen field takes the new coordinates.
+__global__ __launch_bounds__(VEC_BLOCK) void k_residual_copyback(double2* __restrict__ xk, const double2* __restrict__ u, int64_t n,
+                                                                 double* partials) {
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * VEC_BLOCK) {
+        const double2 a = xk[i], b = u[i];
+        const double dx = a.x - b.x, dy = a.y - b.y;
+        acc[0] += dx * dx;
+        acc[1] += dy * dy;
+        xk[i] = b;
+    }
+    block_partials<VEC_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
+}
+hipError_t launch_residual_copyback(double2* xk, const double2* u, int64_t n, double* partials, hipStream_t st) {
+    hipLaunchKernelGGL(k_residual_copyback, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, xk, u, n, partials);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(VEC_BLOCK) void k_gather_rows(const double2* __restrict__ src, const int32_t* __restrict__ ids, int64_t n,
+                                                           double2* __restrict__ dst) {
+    for (int64_t i = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * VEC_BLOCK)
+        dst[i] = src[ids[i]];
+}
+hipError_t launch_gather_rows(const double2* src, const int32_t* ids, int64_t n, double2* dst, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_gather_rows, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, src, ids, n, dst);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_copy_perimeter(const double2* __restrict__ in, double2* __restrict__ out, int ni, int nj) {
+    const int k = blockIdx.x * 256 + threadIdx.x;   // 0..nj-1: row 0, nj..2nj-1: row ni-1, then columns 0 and nj-1 of rows 1..ni-2
+    size_t id;
+    if (k < nj) id = k;
+    else if (k < 2 * nj) id = static_cast<size_t>(ni - 1) * nj + (k - nj);
+    else {
+        const int q = k - 2 * nj;
+        const int i = 1 + (q >> 1);
+        if (i > ni - 2) return;
+        id = static_cast<size_t>(i) * nj + ((q & 1) ? nj - 1 : 0);
+    }
+    out[id] = in[id];
+}
+hipError_t launch_copy_perimeter(const double2* in, double2* out, int ni, int nj, hipStream_t st) {
+    const int n = 2 * nj + 2 * (ni - 2);
+    hipLaunchKernelGGL(k_copy_perimeter, dim3((n + 255) / 256), dim3(256), 0, st, in, out, ni, nj);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// K1 tfi_blend -- reference tfi.zig:112-208 (boundary-blended linear TFI), same term order
+// (types.addAll starts from (0,0) and adds left to right).  Write-only 16 B/node.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 d2_add(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ double2 d2_sub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 d2_scale(double s, double2 v) { return make_double2(s * v.x, s * v.y); }
+
+__global__ __launch_bounds__(256) void k_tfi_block(double2* __restrict__ xy, int n, int m, const double2* __restrict__ x_i_min,
+                                                   const double2* __restrict__ x_i_max, const double2* __restrict__ x_j_min,
+                                                   const double2* __restrict__ x_j_max, const double* __restrict__ s1,
+                                                   const double* __restrict__ s2, const double* __restrict__ t1,
+                                                   const double* __restrict__ t2) {
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int ib = (blockIdx.y * 4 + threadIdx.y) * 4;   // 4 rows per thread: edge-j data reused from registers
+    if (j >= m) return;
+    const double2 x_0_0 = x_i_min[0], x_n_0 = x_i_min[n - 1], x_0_m = x_j_min[m - 1], x_n_m = x_i_max[n - 1];
+    const double t1_j = t1[j], t2_j = t2[j];
+    const double2 x_0_j = x_j_min[j], x_n_j = x_j_max[j];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int i = ib + k;
+        if (i >= n) break;
+        const double s1_i = s1[i], s2_i = s2[i];
+        const double2 x_i_0 = x_i_min[i], x_i_m = x_i_max[i];
+        const double u = ((1.0 - t1_j) * s1_i + t1_j * s2_i) / (1.0 - (s2_i - s1_i) * (t2_j - t1_j));   // tfi.zig:185
+        const double v = ((1.0 - s1_i) * t1_j + s1_i * t2_j) / (1.0 - (t2_j - t1_j) * (s2_i - s1_i));   // tfi.zig:186
+        const double2 u_ij = d2_add(d2_scale(1.0 - u, x_0_j), d2_scale(u, x_n_j));
+        const double2 v_ij = d2_add(d2_scale(1.0 - v, x_i_0), d2_scale(v, x_i_m));
+        double2 uv = make_double2(0.0, 0.0);
+        uv = d2_add(uv, d2_scale(u * v, x_n_m));
+        uv = d2_add(uv, d2_scale(u * (1.0 - v), x_n_0));
+        uv = d2_add(uv, d2_scale((1.0 - u) * v, x_0_m));
+        uv = d2_add(uv, d2_scale((1.0 - u) * (1.0 - v), x_0_0));
+        xy[static_cast<size_t>(i) * m + j] = d2_sub(d2_add(u_ij, v_ij), uv);
+    }
+}
+hipError_t launch_tfi_block(double2* xy, int ni, int nj, const double2* a, const double2* b, const double2* c, const double2* d,
+                            const double* s1, const double* s2, const double* t1, const double* t2, hipStream_t st) {
+    const dim3 block(64, 4), grid((nj + 63) / 64, (ni + 15) / 16);
+    hipLaunchKernelGGL(k_tfi_block, grid, block, 0, st, xy, ni, nj, a, b, c, d, s1, s2, t1, t2);
+    return hipGetLastError();
+}
+
+// tfi.zig:19-67 (plain linear TFI, corners from the i edges)
+__global__ __launch_bounds__(256) void k_tfi_linear2d(double2* __restrict__ xy, int n, int m, const double2* __restrict__ e_i_min,
+                                                      const double2* __restrict__ e_i_max, const double2* __restrict__ e_j_min,
+                                                      const double2* __restrict__ e_j_max) {
+    const int j = blockIdx.x * 64 + threadIdx.x;
+    const int i = blockIdx.y * 4 + threadIdx.y;
+    if (j >= m || i >= n) return;
+    const double2 c00 = e_i_min[0], c10 = e_i_min[n - 1], c01 = e_i_max[0], c11 = e_i_max[n - 1];
+    const double xi = static_cast<double>(i) / static_cast<double>(n - 1);
+    const double eta = static_cast<double>(j) / static_cast<double>(m - 1);
+    const double2 u_ij = d2_add(d2_scale(1.0 - xi, e_j_min[j]), d2_scale(xi, e_j_max[j]));
+    const double2 v_ij = d2_add(d2_scale(1.0 - eta, e_i_min[i]), d2_scale(eta, e_i_max[i]));
+    double2 uv = make_double2(0.0, 0.0);
+    uv = d2_add(uv, d2_scale(xi * eta, c11));
+    uv = d2_add(uv, d2_scale(xi * (1.0 - eta), c10));
+    uv = d2_add(uv, d2_scale((1.0 - xi) * eta, c01));
+    uv = d2_add(uv, d2_scale((1.0 - xi) * (1.0 - eta), c00));
+    double2 res = make_double2(0.0, 0.0);
+    res = d2_add(res, u_ij);
+    res = d2_add(res, v_ij);
+    res = d2_add(res, make_double2(-uv.x, -uv.y));
+    xy[static_cast<size_t>(i) * m + j] = res;
+}
+hipError_t launch_tfi_linear2d(double2* xy, int ni, int nj, const double2* a, const double2* b, const double2* c, const double2* d,
+                               hipStream_t st) {
+    const dim3 block(64, 4), grid((nj + 63) / 64, (ni + 3) / 4);
+    hipLaunchKernelGGL(k_tfi_linear2d, grid, block, 0, st, xy, ni, nj, a, b, c, d);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
+// K6 white control function -- wall_control_function.zig:70-473 (hard-coded to blocks 0,1 and
+// connection 0 like the reference).  wall: one thread per wall node writes (P,Q) at j = 0;
+// le: the leading-edge node of block 0 across connection 0; blend: factor = 1 - j/(nj-1).
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double2 eq610(double x_xi, double y_xi, double x_xi2, double y_xi2, double x_eta, double y_eta,
+                                         double x_eta2, double y_eta2) {
+    const double g11 = x_xi * x_xi + y_xi * y_xi;
+    const double g22 = x_eta * x_eta + y_eta * y_eta;
+    const double p = -(x_xi * x_xi2 + y_xi * y_xi2) / g11 - (x_xi * x_eta2 + y_xi * y_eta2) / g22;
+    const double q = -(x_eta * x_eta2 + y_eta * y_eta2) / g22 - (x_eta * x_xi2 + y_eta * y_xi2) / g11;
+    return make_double2(p, q);
+}
+__device__ __forceinline__ double2 white_delta(double x_xi, double y_xi, double x_eta, double y_eta, double ds_target,
+                                               double theta_target) {   // wall_control_function.zig:293-304
+    const double g11 = x_xi * x_xi + y_xi * y_xi;
+    const double g12 = x_xi * x_eta + y_xi * y_eta;
+    const double g22 = x_eta * x_eta + y_eta * y_eta;
+    const double ds = sqrt(g22);
+    const double theta = acos(g12 / sqrt(g11 * g22));
+    const double delta_ds = ds_target - ds;
+    const double delta_theta = theta_target - theta;
+    return make_double2(-atan2(delta_theta, theta_target), atan2(delta_ds, ds_target));
+}
+
+__global__ void k_white_wall(const double2* __restrict__ d, double2* __restrict__ pq, int ni, int nj, int update, double ds_target,
+                             double theta_target) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= ni) return;
+    const size_t id = static_cast<size_t>(i) * nj;
+    const double2 x0 = d[id], x1 = d[id + 1];
+    const double x_eta = -x0.x + x1.x, y_eta = -x0.y + x1.y;   // forward eta difference
+    double x_xi, y_xi, x_xi2 = 0.0, y_xi2 = 0.0;
+    if (i == 0) {   // forward xi (:86-90, 339-341)
+        const double2 a = d[id + nj];
+        x_xi = -x0.x + a.x;
+        y_xi = -x0.y + a.y;
+        if (!update) {
+            const double2 b = d[id + 2 * static_cast<size_t>(nj)];
+            x_xi2 = x0.x - 2 * a.x + b.x;
+            y_xi2 = x0.y - 2 * a.y + b.y;
+        }
+    } else if (i == ni - 1) {   // backward xi (:165-170, 376-378)
+        const double2 a = d[id - nj];
+        x_xi = x0.x - a.x;
+        y_xi = x0.y - a.y;
+        if (!update) {
+            const double2 b = d[id - 2 * static_cast<size_t>(nj)];
+            x_xi2 = x0.x - 2 * a.x + b.x;
+            y_xi2 = x0.y - 2 * a.y + b.y;
+        }
+    } else {   // central xi (:124-128, 357-359)
+        const double2 xp = d[id + nj], xm = d[id - nj];
+        x_xi = 0.5 * (xp.x - xm.x);
+        y_xi = 0.5 * (xp.y - xm.y);
+        x_xi2 = xp.x - 2 * x0.x + xm.x;
+        y_xi2 = xp.y - 2 * x0.y + xm.y;
+    }
+    if (!update) {
+        const double2 x2 = d[id + 2];
+        const double x_eta2 = x0.x - 2 * x1.x + x2.x, y_eta2 = x0.y - 2 * x1.y + x2.y;
+        pq[id] = eq610(x_xi, y_xi, x_xi2, y_xi2, x_eta, y_eta, x_eta2, y_eta2);
+    } else {
+        const double2 dl = white_delta(x_xi, y_xi, x_eta, y_eta, ds_target, theta_target);
+        double2 v = pq[id];
+        v.x += 0.1 * dl.x;
+        v.y += 0.1 * dl.y;
+        pq[id] = v;
+    }
+}
+__global__ void k_white_le(WhiteArgs w, int update) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    const double2 xij = w.x0[w.le_p0];
+    const double2 xip1 = w.x0[w.le_p0 + w.le_fi0];
+    const double2 xim1 = w.x1[w.le_p1 + w.le_fi1];
+    const double2 xjp1 = w.x0[w.le_p0 + w.le_dir0];
+    const double x_eta = -xij.x + xjp1.x, y_eta = -xij.y + xjp1.y;
+    if (!update) {   // wall_control_function.zig:235-259
+        const double2 xjp2 = w.x0[w.le_p0 + 2 * w.le_dir0];
+        const double x_xi = 0.5 * (xip1.x - xim1.x), y_xi = 0.5 * (xip1.y - xim1.y);
+        const double x_xi2 = xip1.x - 2 * xij.x + xim1.x, y_xi2 = xip1.y - 2 * xij.y + xim1.y;
+        const double x_eta2 = xij.x - 2 * xjp1.x + xjp2.x, y_eta2 = xij.y - 2 * xjp1.y + xjp2.y;
+        w.pq0[0] = eq610(x_xi, y_xi, x_xi2, y_xi2, x_eta, y_eta, x_eta2, y_eta2);
+    } else {   // :423-452, negated xi difference (:428-431)
+        const double x_xi = -0.5 * (xip1.x - xim1.x), y_xi = -0.5 * (xip1.y - xim1.y);
+        const double2 dl = white_delta(x_xi, y_xi, x_eta, y_eta, w.ds_target, w.theta_target);
+        double2 v = w.pq0[0];
+        v.x += 0.1 * dl.x;
+        v.y += 0.1 * dl.y;
+        w.pq0[0] = v;
+    }
+}
+__global__ void k_white_blend(double2* __restrict__ pq, int ni, int nj) {
+    const int j = blockIdx.x * blockDim.x + threadIdx.x;
+    const int i = blockIdx.y;
+    if (j < 1 || j >= nj || i >= ni) return;
+    const double2 wall = pq[static_cast<size_t>(i) * nj];
+    const double factor = 1 - static_cast<double>(j) / (static_cast<double>(nj) - 1);   // :108
+    pq[static_cast<size_t>(i) * nj + j] = make_double2(factor * wall.x, factor * wall.y);
+}
+hipError_t launch_white(const WhiteArgs& w, int update, hipStream_t st) {
+    hipLaunchKernelGGL(k_white_wall, dim3((w.ni0 + 63) / 64), dim3(64), 0, st, w.x0, w.pq0, w.ni0, w.nj0, update, w.ds_target, w.theta_target);
+    hipLaunchKernelGGL(k_white_wall, dim3((w.ni1 + 63) / 64), dim3(64), 0, st, w.x1, w.pq1, w.ni1, w.nj1, update, w.ds_target, w.theta_target);
+    hipLaunchKernelGGL(k_white_le, dim3(1), dim3(64), 0, st, w, update);
+    hipLaunchKernelGGL(k_white_blend, dim3((w.nj0 + 63) / 64, w.ni0), dim3(64), 0, st, w.pq0, w.ni0, w.nj0);
+    hipLaunchKernelGGL(k_white_blend, dim3((w.nj1 + 63) / 64, w.ni1), dim3(64), 0, st, w.pq1, w.ni1, w.nj1);
+    return hipGetLastError();
+}
+
+}  // namespace tmh

@@ -1,0 +1,537 @@
+// Device-resident smoother: the Picard outer loop of reference smooth.zig:74-166 with the
+// per-iteration work (fill, solve, residual, copy-back) replaced by matrix-free gfx950 kernels.
+//
+//   TM_INNER_BICGSTAB  every outer iteration freezes the coordinates X^k, solves
+//                      A(X^k) X^{k+1} = b(X^k) for both components at once with BiCGStab on the
+//                      row-equilibrated operator (recurrences of BiCGStab.zig:279-370, scalars
+//                      device-resident, no host round trip inside an inner iteration), then K7
+//                      computes the reference's residual and copies back (smooth.zig:112-153).
+//   TM_INNER_RELAX     every outer iteration is one fused Jacobi sweep of the nonlinear system.
+#include "tm_smoother.hpp"
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+namespace tmh {
+
+void hip_check(hipError_t e, const char* what) {
+    if (e != hipSuccess) throw TmError(TM_E_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define HIPCHK(x) hip_check((x), #x)
+
+// ------------------------------------------------------------------ arena
+DeviceArena::~DeviceArena() {
+    for (void* p : owned_) (void)hipFree(p);
+}
+void DeviceArena::use_workspace(void* base, uint64_t bytes) {
+    base_ = static_cast<char*>(base);
+    cap_ = bytes;
+    external_ = true;
+}
+void DeviceArena::measure_only() { measure_ = true; }
+void* DeviceArena::alloc(uint64_t bytes) {
+    const uint64_t aligned = (bytes + 255) & ~uint64_t{255};
+    if (measure_) {
+        used_ += aligned;
+        return nullptr;
+    }
+    if (external_) {
+        const uint64_t off = (used_ + 255) & ~uint64_t{255};
+        if (off + aligned > cap_) throw TmError(TM_E_MEMORY, "caller workspace too small (see tm_smoother_workspace_bytes)");
+        used_ = off + aligned;
+        return base_ + off;
+    }
+    void* p = nullptr;
+    if (hipMalloc(&p, aligned ? aligned : 256) != hipSuccess) throw TmError(TM_E_MEMORY, "hipMalloc failed (" + std::to_string(aligned) + " bytes)");
+    owned_.push_back(p);
+    used_ += aligned;
+    return p;
+}
+
+// ------------------------------------------------------------------ helpers
+static Topology topology_from_desc(const tm_mesh_desc* m) {
+    if (!m || !m->blocks || m->nblocks == 0) throw TmError(TM_E_ARG, "mesh description without blocks");
+    if ((m->nconns && !m->conns) || (m->nbcs && !m->bcs)) throw TmError(TM_E_ARG, "null connection / condition array");
+    Topology t;
+    for (uint64_t b = 0; b < m->nblocks; ++b) {
+        t.ni.push_back(static_cast<int64_t>(m->blocks[b].ni));
+        t.nj.push_back(static_cast<int64_t>(m->blocks[b].nj));
+    }
+    auto rng = [](const tm_range& r) {
+        return TopoRange{static_cast<int64_t>(r.block), r.side, static_cast<int64_t>(r.start), static_cast<int64_t>(r.end)};
+    };
+    for (uint64_t c = 0; c < m->nconns; ++c) {
+        TopoConn tc;
+        tc.r[0] = rng(m->conns[c].r[0]);
+        tc.r[1] = rng(m->conns[c].r[1]);
+        tc.periodic = m->conns[c].has_periodicity != 0;
+        tc.per[0] = m->conns[c].periodicity[0];
+        tc.per[1] = m->conns[c].periodicity[1];
+        t.conns.push_back(tc);
+    }
+    for (uint64_t c = 0; c < m->nbcs; ++c) t.bcs.push_back(TopoCond{rng(m->bcs[c].range), m->bcs[c].kind});
+    try {
+        t.finalize();
+    } catch (const PlanError& e) {
+        throw TmError(e.code, e.what());
+    }
+    return t;
+}
+
+static void check_desc_matches(const Topology& t, const tm_mesh_desc* m) {
+    if (!m || static_cast<int64_t>(m->nblocks) != t.nblocks()) throw TmError(TM_E_SIZE, "mesh description does not match the handle");
+    for (int64_t b = 0; b < t.nblocks(); ++b)
+        if (static_cast<int64_t>(m->blocks[b].ni) != t.ni[b] || static_cast<int64_t>(m->blocks[b].nj) != t.nj[b])
+            throw TmError(TM_E_SIZE, "block sizes do not match the handle");
+}
+
+// smooth.zig:220-275: both sides of every connection must coincide within 1e-15
+static void connection_data_check(const Topology& t, const tm_mesh_desc* m, const std::vector<int32_t>& owner, int rank) {
+    const double abs_tol = 1e-15;
+    for (size_t c = 0; c < t.conns.size(); ++c) {
+        const TopoConn& conn = t.conns[c];
+        if (owner[conn.r[0].block] != rank || owner[conn.r[1].block] != rank) continue;   // remote side: not visible here
+        const ConnShifts s = conn_shifts(t, conn);
+        const double* a = m->blocks[conn.r[0].block].xy;
+        const double* b = m->blocks[conn.r[1].block].xy;
+        for (int64_t k = 0; k < s.count; ++k) {
+            const int64_t p0 = s.position[0] + k * s.direction[0], p1 = s.position[1] + k * s.direction[1];
+            double x0 = a[2 * p0], y0 = a[2 * p0 + 1];
+            if (conn.periodic) {
+                x0 = x0 + conn.per[0];
+                y0 = y0 + conn.per[1];
+            }
+            if (!(std::fabs(x0 - b[2 * p1]) <= abs_tol && std::fabs(y0 - b[2 * p1 + 1]) <= abs_tol))
+                throw TmError(TM_E_MISMATCH, "non matching points for connection " + std::to_string(c) + " point " + std::to_string(k));
+        }
+    }
+}
+
+void Smoother::sync() { HIPCHK(hipStreamSynchronize(stream)); }
+
+// ------------------------------------------------------------------ create
+void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm_control_fn* c, const tm_comm_hooks* h, void* strm,
+                      bool measure) {
+    if (!o) throw TmError(TM_E_ARG, "null solver option");
+    if (o->tag != TM_SOLVER_HIP)
+        throw TmError(TM_E_UNSUPPORTED, "ExternalSolverNotEnabled: libtm_hip serves only solver tag `hip` (gmres/bicgstab/umfpack/petsc stay on the Zig side)");
+    if (o->inner != TM_INNER_BICGSTAB && o->inner != TM_INNER_RELAX) throw TmError(TM_E_ARG, "unknown inner strategy");
+    opt = *o;
+    if (!(opt.rtol > 0)) opt.rtol = 1e-12;
+    if (!(opt.atol > 0)) opt.atol = 0.0;
+    if (opt.max_inner == 0) opt.max_inner = 1000;
+    if (opt.check_every == 0) opt.check_every = 8;
+    if (!(opt.omega > 0)) opt.omega = 1.0;
+    cf = c ? *c : tm_control_fn{TM_CF_LAPLACE, 0, 0.0, 0.0};
+    if (cf.kind != TM_CF_LAPLACE && cf.kind != TM_CF_WHITE) throw TmError(TM_E_ARG, "unknown control function");
+    stream = static_cast<hipStream_t>(strm);
+
+    topo = topology_from_desc(mesh);
+    dof_global = topo.dof;
+    try {
+        all_rows = build_rows(topo);
+        has_hooks = h != nullptr && h->nranks > 1;
+        if (h) hooks = *h;
+        owner.assign(topo.nblocks(), 0);
+        int rank = 0, nranks = 1;
+        if (has_hooks) {
+            if (!h->owner || !h->exchange || !h->allreduce_sum) throw TmError(TM_E_ARG, "multi-rank hooks need owner, exchange and allreduce_sum");
+            rank = h->rank;
+            nranks = h->nranks;
+            owner.assign(h->owner, h->owner + topo.nblocks());
+        }
+        lp = build_local_plan(topo, all_rows, owner, rank, nranks);
+    } catch (const PlanError& e) {
+        throw TmError(e.code, e.what());
+    }
+    n_owned = lp.n_owned;
+    n_ghost = static_cast<int64_t>(lp.ghost_gid.size());
+    n_local = n_owned + n_ghost;
+    if (n_owned == 0) throw TmError(TM_E_ARG, "this rank owns no block");
+
+    white = cf.kind == TM_CF_WHITE;
+    if (white) {   // wall_control_function.zig:72, 204-217: hard-coded to blocks 0,1 and connection 0
+        if (topo.nblocks() < 2 || topo.conns.empty()) throw TmError(TM_E_TOPOLOGY, "white control function needs the O4H layout (blocks 0,1 + connection 0)");
+        const TopoConn& c0 = topo.conns[0];
+        if (!(c0.r[0].block == 0 && c0.r[0].start == 0 && c0.r[0].side == SIDE_J_MIN && c0.r[1].block == 1 && c0.r[1].start == 0 &&
+              c0.r[1].side == SIDE_J_MIN && !c0.periodic))
+            throw TmError(TM_E_TOPOLOGY, "white control function: connection 0 must join blocks 0 and 1 at j_min, start 0, without periodicity");
+        if (owner[0] != lp.rank || owner[1] != lp.rank) throw TmError(TM_E_UNSUPPORTED, "white control function: blocks 0 and 1 must live on the same rank");
+        white_le = conn_shifts(topo, c0);
+    }
+
+    if (measure) arena.measure_only();
+    else if (h && h->workspace) arena.use_workspace(h->workspace, h->workspace_bytes);
+
+    // ---- vectors
+    auto vec = [&]() { return arena.alloc_n<double2>(static_cast<uint64_t>(n_local)); };
+    X = vec();
+    U = vec();
+    if (opt.inner == TM_INNER_BICGSTAB) {
+        r = vec();
+        r_hat = vec();
+        p = vec();
+        v = vec();
+        s = vec();
+        t = vec();
+    }
+    if (white) PQ = vec();
+
+    // ---- perimeter rows -> device SoA with rank-local ids
+    const size_t nr = lp.rows.size();
+    std::vector<int32_t> h_row(nr), h_cols(nr * 9, 0), h_metric(nr * 4, 0);
+    std::vector<int8_t> h_kind(nr), h_ncols(nr), h_slot(nr * 9, 0), h_self(nr);
+    std::vector<double> h_cx(nr * 9, 0.0), h_cy(nr * 9, 0.0), h_per(nr * 2, 0.0);
+    std::vector<uint8_t> h_flags(nr);
+    for (size_t k = 0; k < nr; ++k) {
+        const PlanRow& pr = lp.rows[k];
+        auto loc = [&](int64_t gid) {
+            const int64_t l = lp.to_local(gid);
+            if (l < 0) throw TmError(TM_E_TOPOLOGY, "internal: column is neither owned nor ghost");
+            return static_cast<int32_t>(l);
+        };
+        h_row[k] = loc(pr.gid);
+        h_kind[k] = pr.kind;
+        h_ncols[k] = pr.ncols;
+        h_self[k] = pr.self;
+        h_flags[k] = pr.flags;
+        h_per[2 * k] = pr.per[0];
+        h_per[2 * k + 1] = pr.per[1];
+        for (int q = 0; q < pr.ncols; ++q) {
+            h_cols[k * 9 + q] = loc(pr.col[q]);
+            h_cx[k * 9 + q] = pr.cx[q];
+            h_cy[k * 9 + q] = pr.cy[q];
+            h_slot[k * 9 + q] = pr.slot[q];
+        }
+        if (pr.kind == KIND_SMOOTHED)
+            for (int q = 0; q < 4; ++q) h_metric[k * 4 + q] = loc(pr.metric[q]);
+    }
+    h_rhs.assign(nr * 2, 0.0);
+    auto up = [&](const void* src, uint64_t bytes) -> void* {
+        void* d = arena.alloc(bytes);
+        if (!measure && bytes) HIPCHK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
+        return d;
+    };
+    edge.nrows = static_cast<int>(nr);
+    edge.row = static_cast<int32_t*>(up(h_row.data(), nr * 4));
+    edge.kind = static_cast<int8_t*>(up(h_kind.data(), nr));
+    edge.ncols = static_cast<int8_t*>(up(h_ncols.data(), nr));
+    edge.cols = static_cast<int32_t*>(up(h_cols.data(), nr * 9 * 4));
+    edge.cx = static_cast<double*>(up(h_cx.data(), nr * 9 * 8));
+    edge.cy = static_cast<double*>(up(h_cy.data(), nr * 9 * 8));
+    edge.slot = static_cast<int8_t*>(up(h_slot.data(), nr * 9));
+    edge.metric = static_cast<int32_t*>(up(h_metric.data(), nr * 4 * 4));
+    edge.per = static_cast<double*>(up(h_per.data(), nr * 2 * 8));
+    edge.flags = static_cast<uint8_t*>(up(h_flags.data(), nr));
+    edge.self = static_cast<int8_t*>(up(h_self.data(), nr));
+    d_rhs = arena.alloc_n<double>(nr * 2);
+    edge.rhs = d_rhs;
+
+    // ---- reductions
+    poff.clear();
+    int off = 0;
+    for (int64_t b : lp.owned_blocks) {
+        poff.push_back(off);
+        off += apply_block_nwg(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
+    }
+    poff_edge = off;
+    off += edge_rows_nwg(edge.nrows);
+    nwg_apply = off;
+    nwg_vec = vec_nwg(n_owned);
+    partials = arena.alloc_n<double>(static_cast<uint64_t>(std::max(nwg_apply, nwg_vec)) * MAX_PARTIALS);
+    red = arena.alloc_n<double>(MAX_PARTIALS);
+    S = arena.alloc_n<KrylovScalars>(1);
+
+    // ---- halo exchange
+    n_send = static_cast<int64_t>(lp.send_ids.size());
+    if (n_send) {
+        d_send_ids = static_cast<int32_t*>(up(lp.send_ids.data(), static_cast<uint64_t>(n_send) * 4));
+        d_send_buf = arena.alloc_n<double2>(static_cast<uint64_t>(n_send));
+    }
+    if (measure) return;
+
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_S), sizeof(KrylovScalars), hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_red), sizeof(double) * MAX_PARTIALS, hipHostMallocDefault));
+    HIPCHK(hipMemsetAsync(S, 0, sizeof(KrylovScalars), stream));
+    if (PQ) HIPCHK(hipMemsetAsync(PQ, 0, sizeof(double2) * n_local, stream));
+    upload(mesh);
+    if (white) white_launch(0);   // ControlFunction.init, wall_control_function.zig:27-42
+    sync();
+}
+
+// ------------------------------------------------------------------ upload / download
+void Smoother::upload(const tm_mesh_desc* mesh) {
+    check_desc_matches(topo, mesh);
+    for (int64_t b : lp.owned_blocks)
+        if (!mesh->blocks[b].xy) throw TmError(TM_E_ARG, "owned block without coordinates");
+    connection_data_check(topo, mesh, owner, lp.rank);
+    for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
+        const int64_t b = lp.owned_blocks[k];
+        HIPCHK(hipMemcpyAsync(X + lp.local_start[k], mesh->blocks[b].xy, sizeof(double2) * topo.ni[b] * topo.nj[b], hipMemcpyHostToDevice, stream));
+    }
+    // static right-hand sides: fixed rows keep the boundary coordinates, sliding rows the boundary x (smooth.zig:794-795, 853-858)
+    for (size_t k = 0; k < lp.rows.size(); ++k) {
+        const PlanRow& pr = lp.rows[k];
+        h_rhs[2 * k] = pr.rhs[0];
+        h_rhs[2 * k + 1] = pr.rhs[1];
+        if (pr.rhs_coord) {
+            int64_t b = topo.nblocks() - 1;
+            while (pr.gid < topo.start[b]) --b;
+            const double* xy = mesh->blocks[b].xy + 2 * (pr.gid - topo.start[b]);
+            if (pr.rhs_coord & 1) h_rhs[2 * k] = xy[0];
+            if (pr.rhs_coord & 2) h_rhs[2 * k + 1] = xy[1];
+        }
+    }
+    if (!h_rhs.empty()) HIPCHK(hipMemcpyAsync(d_rhs, h_rhs.data(), sizeof(double) * h_rhs.size(), hipMemcpyHostToDevice, stream));
+    sync();   // host staging buffers may go away after return
+}
+
+void Smoother::download(const tm_mesh_desc* mesh) {
+    check_desc_matches(topo, mesh);
+    for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
+        const int64_t b = lp.owned_blocks[k];
+        if (!mesh->blocks[b].xy) throw TmError(TM_E_ARG, "owned block without coordinates");
+        HIPCHK(hipMemcpyAsync(mesh->blocks[b].xy, X + lp.local_start[k], sizeof(double2) * topo.ni[b] * topo.nj[b], hipMemcpyDeviceToHost, stream));
+    }
+    sync();
+}
+
+// ------------------------------------------------------------------ building blocks
+void Smoother::exchange(double2* vec) {
+    if (!has_hooks || (n_send == 0 && n_ghost == 0)) return;
+    HIPCHK(launch_gather_rows(vec, d_send_ids, n_send, d_send_buf, stream));
+    const int rc = hooks.exchange(hooks.ctx, reinterpret_cast<const double*>(d_send_buf), reinterpret_cast<double*>(vec + n_owned), stream);
+    if (rc != 0) throw TmError(TM_E_COMM, "halo exchange hook failed with code " + std::to_string(rc));
+}
+
+void Smoother::reduce(int nwg) {
+    HIPCHK(launch_finalize(partials, nwg, red, stream));
+    if (has_hooks) {
+        const int rc = hooks.allreduce_sum(hooks.ctx, red, MAX_PARTIALS, stream);
+        if (rc != 0) throw TmError(TM_E_COMM, "all-reduce hook failed with code " + std::to_string(rc));
+    }
+}
+
+void Smoother::apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega) {
+    exchange(const_cast<double2*>(in));
+    for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
+        const int64_t b = lp.owned_blocks[k];
+        const int64_t ls = lp.local_start[k];
+        ApplyBlock a;
+        a.in = in + ls;
+        a.xk = xk + ls;
+        a.pq = PQ ? PQ + ls : nullptr;
+        a.aux = aux ? aux + ls : nullptr;
+        a.out = out + ls;
+        a.ni = static_cast<int>(topo.ni[b]);
+        a.nj = static_cast<int>(topo.nj[b]);
+        a.omega = omega;
+        a.partials = partials + static_cast<size_t>(poff[k]) * MAX_PARTIALS;
+        if (profile) {
+            if (ev_used == ev_start.size()) {
+                hipEvent_t e0, e1;
+                HIPCHK(hipEventCreate(&e0));
+                HIPCHK(hipEventCreate(&e1));
+                ev_start.push_back(e0);
+                ev_stop.push_back(e1);
+            }
+            HIPCHK(hipEventRecord(ev_start[ev_used], stream));
+            HIPCHK(launch_apply_block(a, mode, dot, stream));
+            HIPCHK(hipEventRecord(ev_stop[ev_used], stream));
+            ev_used += 1;
+        } else {
+            HIPCHK(launch_apply_block(a, mode, dot, stream));
+        }
+    }
+    HIPCHK(launch_edge_rows(edge, in, xk, PQ, aux, out, omega, mode, dot, partials + static_cast<size_t>(poff_edge) * MAX_PARTIALS, stream));
+    if (dot != DOT_NONE) reduce(nwg_apply);
+}
+
+void Smoother::white_launch(int update) {
+    WhiteArgs w;
+    const auto idx = [&](int64_t b) { return lp.local_start[std::lower_bound(lp.owned_blocks.begin(), lp.owned_blocks.end(), b) - lp.owned_blocks.begin()]; };
+    w.x0 = X + idx(0);
+    w.x1 = X + idx(1);
+    w.pq0 = PQ + idx(0);
+    w.pq1 = PQ + idx(1);
+    w.ni0 = static_cast<int>(topo.ni[0]);
+    w.nj0 = static_cast<int>(topo.nj[0]);
+    w.ni1 = static_cast<int>(topo.ni[1]);
+    w.nj1 = static_cast<int>(topo.nj[1]);
+    w.le_p0 = static_cast<int>(white_le.position[0]);
+    w.le_p1 = static_cast<int>(white_le.position[1]);
+    w.le_fi0 = static_cast<int>(white_le.first_internal[0]);
+    w.le_fi1 = static_cast<int>(white_le.first_internal[1]);
+    w.le_dir0 = static_cast<int>(white_le.direction[0]);
+    w.ds_target = cf.ds_target;
+    w.theta_target = cf.theta_target;
+    HIPCHK(launch_white(w, update, stream));
+}
+
+// ------------------------------------------------------------------ Picard + BiCGStab
+// One outer iteration: returns 1 if the inner solve did not converge.
+int Smoother::picard_bicgstab(tm_stats& st) {
+    if (white && outer_done > 0) white_launch(1);   // system.fill(n): control_function.update for n > 0 (smooth.zig:1107-1110)
+    exchange(X);
+    // warm start: the solution vector starts from the current coordinates (BiCGStab.zig:136-153; later
+    // outer iterations continue from the copied-back solution, which is the same field)
+    HIPCHK(hipMemcpyAsync(U, X, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));
+    // tolerance from ||D^-1 b||
+    HIPCHK(launch_edge_rhs(edge, X, PQ, nullptr, 1, partials, stream));
+    reduce(edge_rows_nwg(edge.nrows));
+    HIPCHK(launch_scalar_update(S, red, STEP_TOL, stream, opt.rtol, opt.atol));
+
+    int restarts = 0;
+    uint64_t it_total = 0;
+    bool converged = false;
+    while (true) {
+        // r = D^-1 (b - A U) ; r_hat = r ; p = v = 0
+        apply(U, r, MODE_RESID, DOT_OUT2, nullptr, X, 0.0);
+        st.operator_sweeps += 1;
+        HIPCHK(launch_scalar_update(S, red, STEP_INIT, stream));
+        HIPCHK(hipMemcpyAsync(r_hat, r, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemsetAsync(p, 0, sizeof(double2) * n_local, stream));
+        HIPCHK(hipMemsetAsync(v, 0, sizeof(double2) * n_local, stream));
+        if (restarts == 0) {   // scaled nonlinear residual of this outer iteration
+            HIPCHK(hipMemcpyAsync(h_S, S, sizeof(KrylovScalars), hipMemcpyDeviceToHost, stream));
+            sync();
+            st.scaled_residual_rms = std::sqrt((h_S->rr0[0] + h_S->rr0[1]) / (2.0 * static_cast<double>(dof_global)));
+            if (h_S->done[0] == 1 && h_S->done[1] == 1) {
+                converged = true;
+                break;
+            }
+        }
+        bool breakdown = false;
+        while (it_total < opt.max_inner) {
+            HIPCHK(launch_p_update(S, r, p, v, n_owned, stream));
+            apply(p, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0);
+            HIPCHK(launch_scalar_update(S, red, STEP_SIGMA, stream));
+            HIPCHK(launch_s_update(S, r, v, s, n_owned, partials, stream));
+            reduce(nwg_vec);
+            HIPCHK(launch_scalar_update(S, red, STEP_SS, stream));
+            apply(s, t, MODE_SCALED, DOT_IN, nullptr, X, 0.0);
+            HIPCHK(launch_scalar_update(S, red, STEP_TSTT, stream));
+            HIPCHK(launch_xr_update(S, U, p, s, t, r, r_hat, n_owned, partials, stream));
+            reduce(nwg_vec);
+            HIPCHK(launch_scalar_update(S, red, STEP_RHO, stream));
+            st.operator_sweeps += 2;
+            it_total += 1;
+            if (it_total % opt.check_every == 0 || it_total == opt.max_inner) {
+                HIPCHK(hipMemcpyAsync(h_S, S, sizeof(KrylovScalars), hipMemcpyDeviceToHost, stream));
+                sync();
+                if (h_S->done[0] && h_S->done[1]) {
+                    converged = h_S->done[0] == 1 && h_S->done[1] == 1;
+                    breakdown = !converged;
+                    break;
+                }
+            }
+        }
+        if (converged || !breakdown || restarts >= 8 || it_total >= opt.max_inner) break;
+        restarts += 1;   // breakdown (rho or omega vanished): restart from the current iterate
+    }
+    st.inner_iterations += it_total;
+
+    // residual + copy-back (smooth.zig:112-153); X becomes the new frozen field
+    HIPCHK(launch_residual_copyback(X, U, n_owned, partials, stream));
+    reduce(nwg_vec);
+    HIPCHK(hipMemcpyAsync(h_red, red, sizeof(double) * MAX_PARTIALS, hipMemcpyDeviceToHost, stream));
+    sync();
+    st.last_dx2 = h_red[0];
+    st.last_dy2 = h_red[1];
+    st.last_residual = (h_red[0] + h_red[1]) * (h_red[0] + h_red[1]);   // smooth.zig:136
+    outer_done += 1;
+    return converged ? 0 : 1;
+}
+
+void Smoother::relax_sweeps(uint64_t n, tm_stats& st) {
+    for (uint64_t k = 0; k < n; ++k) {
+        if (white && outer_done > 0) white_launch(1);
+        // one fused sweep: U = X + omega D^-1 (b - A(X) X), partial sums of (U - X)^2
+        apply(X, U, MODE_RELAX, DOT_DELTA, nullptr, X, opt.omega);
+        std::swap(X, U);
+        st.operator_sweeps += 1;
+        outer_done += 1;
+    }
+    if (n) {
+        HIPCHK(hipMemcpyAsync(h_red, red, sizeof(double) * MAX_PARTIALS, hipMemcpyDeviceToHost, stream));
+        sync();
+        st.last_dx2 = h_red[0];
+        st.last_dy2 = h_red[1];
+        st.last_residual = (h_red[0] + h_red[1]) * (h_red[0] + h_red[1]);
+        // for a Jacobi sweep the displacement is omega times the scaled residual
+        st.scaled_residual_rms = std::sqrt((h_red[0] + h_red[1]) / (2.0 * static_cast<double>(dof_global))) / opt.omega;
+    }
+}
+
+void Smoother::iterate(uint64_t iterations, tm_stats* stats) {
+    const auto t0 = std::chrono::steady_clock::now();
+    tm_stats st;
+    std::memset(&st, 0, sizeof(st));
+    if (opt.inner == TM_INNER_RELAX) {
+        relax_sweeps(iterations, st);
+        st.outer_iterations = iterations;
+    } else {
+        for (uint64_t n = 0; n < iterations; ++n) {
+            st.not_converged += picard_bicgstab(st);
+            st.outer_iterations += 1;
+        }
+    }
+    sync();
+    st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) *stats = st;
+}
+
+void Smoother::profile_read(double* ms_total, uint64_t* launches) {
+    sync();
+    double total = 0.0;
+    for (size_t k = 0; k < ev_used; ++k) {
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, ev_start[k], ev_stop[k]));
+        total += ms;
+    }
+    if (ms_total) *ms_total = total;
+    if (launches) *launches = ev_used;
+    ev_used = 0;
+}
+
+// ------------------------------------------------------------------ introspection
+void Smoother::ensure_tmp() {
+    if (tmpA) return;
+    if (r && v) {   // BiCGStab workspaces are free between iterate() calls
+        tmpA = r;
+        tmpB = v;
+        return;
+    }
+    tmpA = arena.alloc_n<double2>(static_cast<uint64_t>(n_local));
+    tmpB = arena.alloc_n<double2>(static_cast<uint64_t>(n_local));
+}
+
+void Smoother::apply_host(const double* in_xy, double* out_xy, int scaled) {
+    if (has_hooks) throw TmError(TM_E_UNSUPPORTED, "tm_smoother_apply is available on single-process handles only");
+    ensure_tmp();
+    HIPCHK(hipMemcpyAsync(tmpA, in_xy, sizeof(double2) * n_owned, hipMemcpyHostToDevice, stream));
+    apply(tmpA, tmpB, scaled ? MODE_SCALED : MODE_RAW, DOT_NONE, nullptr, X, 0.0);
+    HIPCHK(hipMemcpyAsync(out_xy, tmpB, sizeof(double2) * n_owned, hipMemcpyDeviceToHost, stream));
+    sync();
+}
+
+void Smoother::rhs_host(double* rhs_xy) {
+    if (has_hooks) throw TmError(TM_E_UNSUPPORTED, "tm_smoother_rhs is available on single-process handles only");
+    ensure_tmp();
+    HIPCHK(hipMemsetAsync(tmpA, 0, sizeof(double2) * n_local, stream));
+    HIPCHK(launch_edge_rhs(edge, X, PQ, tmpA, 0, nullptr, stream));
+    HIPCHK(hipMemcpyAsync(rhs_xy, tmpA, sizeof(double2) * n_owned, hipMemcpyDeviceToHost, stream));
+    sync();
+}
+
+void Smoother::control_function_host(double* pq) {
+    if (!PQ) {
+        std::memset(pq, 0, sizeof(double) * 2 * n_owned);
+        return;
+    }
+    HIPCHK(hipMemcpyAsync(pq, PQ, sizeof(double2) * n_owned, hipMemcpyDeviceToHost, stream));
+    sync();
+}
+
+}  // namespace tmh

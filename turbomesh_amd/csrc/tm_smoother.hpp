@@ -1,0 +1,106 @@
+// Device-resident smoother handle (internal).  One handle = one rank's share of a mesh.
+#pragma once
+#include "../../include/tm_hip.h"
+#include "tm_kernels.h"
+#include "tm_plan.hpp"
+#include <memory>
+#include <string>
+#include <vector>
+
+namespace tmh {
+
+struct TmError : std::runtime_error {
+    int code;
+    TmError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
+};
+void hip_check(hipError_t e, const char* what);
+
+// Bump allocator over either library-owned hipMalloc chunks or a caller-provided workspace.
+class DeviceArena {
+   public:
+    DeviceArena() = default;
+    ~DeviceArena();
+    void use_workspace(void* base, uint64_t bytes);   // carve from caller memory
+    void measure_only();                              // only count bytes (tm_smoother_workspace_bytes)
+    void* alloc(uint64_t bytes);
+    template <class T>
+    T* alloc_n(uint64_t n) { return static_cast<T*>(alloc(n * sizeof(T))); }
+    uint64_t used() const { return used_; }
+    bool measuring() const { return measure_; }
+
+   private:
+    std::vector<void*> owned_;
+    char* base_ = nullptr;
+    uint64_t cap_ = 0, used_ = 0;
+    bool external_ = false, measure_ = false;
+};
+
+struct Smoother {
+    Topology topo;
+    std::vector<PlanRow> all_rows;
+    LocalPlan lp;
+    tm_solver_opt opt{};
+    tm_control_fn cf{};
+    tm_comm_hooks hooks{};
+    bool has_hooks = false;
+    std::vector<int32_t> owner;
+    hipStream_t stream = nullptr;
+    DeviceArena arena;
+
+    int64_t n_owned = 0, n_local = 0, n_ghost = 0, dof_global = 0;
+    // vectors, double2[n_local]
+    double2 *X = nullptr, *U = nullptr, *r = nullptr, *r_hat = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *t = nullptr;
+    double2 *PQ = nullptr, *tmpA = nullptr, *tmpB = nullptr;
+    // perimeter rows
+    EdgeRowsDev edge;
+    std::vector<double> h_rhs;   // host copy of the static rhs (refilled on upload)
+    double* d_rhs = nullptr;
+    // reductions
+    double* partials = nullptr;
+    double* red = nullptr;
+    KrylovScalars* S = nullptr;
+    KrylovScalars* h_S = nullptr;   // pinned
+    double* h_red = nullptr;        // pinned
+    std::vector<int> poff;          // partial-row offset of each owned block's K2 launch
+    int poff_edge = 0, nwg_apply = 0, nwg_vec = 0;
+    // halo exchange
+    int32_t* d_send_ids = nullptr;
+    double2* d_send_buf = nullptr;
+    int64_t n_send = 0;
+    // white control function
+    bool white = false;
+    ConnShifts white_le{};
+    uint64_t outer_done = 0;
+    // measurement: HIP event pairs around K2 launches
+    bool profile = false;
+    std::vector<hipEvent_t> ev_start, ev_stop;
+    size_t ev_used = 0;
+    void profile_read(double* ms_total, uint64_t* launches);
+
+    void create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm_control_fn* c, const tm_comm_hooks* h, void* strm,
+                bool measure);
+    void upload(const tm_mesh_desc* mesh);
+    void download(const tm_mesh_desc* mesh);
+    void iterate(uint64_t iterations, tm_stats* stats);
+    void apply_host(const double* in_xy, double* out_xy, int scaled);
+    void rhs_host(double* rhs_xy);
+    void control_function_host(double* pq);
+
+    // building blocks
+    void exchange(double2* vec);
+    void apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega);
+    void reduce(int nwg);   // partials -> red (+ all-reduce)
+    void white_launch(int update);
+    void sync();
+    void ensure_tmp();
+
+   private:
+    int picard_bicgstab(tm_stats& st);
+    void relax_sweeps(uint64_t n, tm_stats& st);
+};
+
+}  // namespace tmh
+
+struct tm_smoother {
+    tmh::Smoother impl;
+};

@@ -1,0 +1,107 @@
+"""Mirror of reference src/core/discrete.zig: Edge, EdgeView, Block2d, Mesh."""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import List
+
+import numpy as np
+
+from . import clustering as cluster
+from . import tfi
+from .boundary import Condition, Connection
+from .types import Mat2d, eqlApprox
+
+
+class Edge:
+    """discrete.zig:12-36: points (n,2) + clustering (n)."""
+
+    def __init__(self, points, clustering):
+        self.points = np.ascontiguousarray(points, dtype=np.float64)
+        self.clustering = np.ascontiguousarray(clustering, dtype=np.float64)
+
+    @classmethod
+    def init(cls, n, curve, clustering):
+        u = cluster.create(clustering, n)
+        return cls(curve.interpolate(u), u)
+
+    @staticmethod
+    def combine(edges: "List[EdgeView]") -> "Edge":
+        """discrete.zig:38-91: concatenate views, renormalise the cumulative clustering."""
+        assert len(edges) > 1
+        tol = 1e-10
+        for i in range(len(edges) - 1):
+            e, nx = edges[i], edges[i + 1]
+            if not eqlApprox(e.edge.points[e.end], nx.edge.points[nx.start], tol):
+                raise ValueError(f"edges {i + 1} and {i + 2} cannot be combined as end points do not match")
+        n = sum(e.len() for e in edges) - (len(edges) - 1)
+        u = np.empty(n)
+        pts = np.empty((n, 2))
+        start = 0
+        for e in edges:
+            start += e.clonePoints(pts[start:]) - 1
+        start, last_value = 0, 0.0
+        for e in edges:
+            start += e.cloneClustering(u[start:], last_value) - 1
+            last_value = u[start]
+        u /= last_value
+        return Edge(pts, u)
+
+
+@dataclass
+class EdgeView:
+    """discrete.zig:94-136"""
+
+    edge: Edge
+    start: int
+    end: int
+
+    def len(self):
+        return abs(self.end - self.start) + 1
+
+    def clonePoints(self, buffer):
+        n = self.len()
+        if self.start > self.end:
+            buffer[:n] = self.edge.points[self.end:self.start + 1][::-1]
+        else:
+            buffer[:n] = self.edge.points[self.start:self.end + 1]
+        return n
+
+    def cloneClustering(self, buffer, initial_value):
+        buffer[0] = initial_value
+        first, last = (self.end, self.start) if self.start > self.end else (self.start, self.end)
+        base = self.edge.clustering[first]
+        k = 1
+        for i in range(first + 1, last + 1):
+            buffer[k] = initial_value + (self.edge.clustering[i] - base)
+            k += 1
+        return k
+
+
+class Block2d:
+    """discrete.zig:138-164: allocates the Mat2d and seeds it by TFI (on the GPU)."""
+
+    def __init__(self, points: Mat2d):
+        self.points = points
+
+    @classmethod
+    def init(cls, i_min: Edge, i_max: Edge, j_min: Edge, j_max: Edge) -> "Block2d":
+        assert len(i_min.points) == len(i_max.points)
+        assert len(j_min.points) == len(j_max.points)
+        points = Mat2d((len(i_min.points), len(j_min.points)))
+        tfi.linear2dBoundaryBlendedControlFunction(points, i_min.points, i_max.points, j_min.points, j_max.points, i_min.clustering,
+                                                   i_max.clustering, j_min.clustering, j_max.clustering)
+        return cls(points)
+
+
+@dataclass
+class Mesh:
+    """discrete.zig:166-195"""
+
+    blocks: List[Block2d] = field(default_factory=list)
+    names: List[str] = field(default_factory=list)
+    connections: List[Connection] = field(default_factory=list)
+    boundary_conditions: List[Condition] = field(default_factory=list)
+
+    def addBlock(self, name, block):
+        self.blocks.append(block)
+        self.names.append(name)

@@ -1,0 +1,128 @@
+"""Mirror of reference src/core/smoothing/smooth.zig: mesh(mesh_data, iterations, solver_option,
+control_function_algorithm) -- executed on the MI355X through libtm_hip.so.
+
+`Smoother` is the persistent-handle form (coordinates stay in HBM between calls)."""
+from __future__ import annotations
+
+import ctypes as C
+import logging
+
+import numpy as np
+
+from .. import _capi
+from . import solver as _solver
+from . import wall_control_function as _wcf
+
+log = logging.getLogger("smoothing")   # std.log.scoped(.smoothing), smooth.zig:58
+
+
+def mesh(mesh_data, iterations: int, solver_option: "_solver.Option | None" = None,
+         control_function_algorithm: "_wcf.Algorithm | None" = None):
+    """smooth.zig:74-166: mutates mesh_data.blocks[b].points.data in place; returns the stats."""
+    opt = (solver_option or _solver.Option.hip()).c_struct()
+    cf = (control_function_algorithm or _wcf.Algorithm.laplace()).c_struct()
+    md = _capi.MeshDesc(mesh_data)
+    st = _capi.tm_stats()
+    rc = _capi.check(_capi.lib().tm_smooth_mesh(md.ref(), iterations, C.byref(opt), C.byref(cf), C.byref(st)))
+    if rc == _capi.TM_W_NOT_CONVERGED:
+        log.warning("hip solve did not converge in %d of %d outer iterations", st.not_converged, st.outer_iterations)
+    if iterations:
+        log.info("\tresidual: %r", st.last_residual)
+    log.info("elapsed time for smoothing: %.2f s", st.seconds)
+    return st.as_dict()
+
+
+class Smoother:
+    """tm_smoother_* handle: upload once, iterate on the device, download when needed."""
+
+    def __init__(self, mesh_data, solver_option=None, control_function_algorithm=None, hooks=None, stream=None):
+        self._mesh = mesh_data
+        self._md = _capi.MeshDesc(mesh_data)
+        opt = (solver_option or _solver.Option.hip()).c_struct()
+        cf = (control_function_algorithm or _wcf.Algorithm.laplace()).c_struct()
+        h = C.c_void_p()
+        self._hooks = hooks
+        _capi.check(_capi.lib().tm_smoother_create(self._md.ref(), C.byref(opt), C.byref(cf), C.byref(hooks) if hooks is not None else None,
+                                                   C.c_void_p(stream) if stream else None, C.byref(h)))
+        self._h = h
+        self.dof = int(_capi.lib().tm_smoother_dof(self._h))
+
+    def close(self):
+        if getattr(self, "_h", None):
+            _capi.lib().tm_smoother_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def iterate(self, iterations: int):
+        st = _capi.tm_stats()
+        _capi.check(_capi.lib().tm_smoother_iterate(self._h, iterations, C.byref(st)))
+        return st.as_dict()
+
+    def download(self):
+        _capi.check(_capi.lib().tm_smoother_download(self._h, self._md.ref()))
+
+    def upload(self):
+        _capi.check(_capi.lib().tm_smoother_upload(self._h, self._md.ref()))
+
+    def apply(self, vec, scaled=False):
+        """out = A(X) vec (optionally row-equilibrated) for a (dof, 2) host array."""
+        vec = np.ascontiguousarray(vec, dtype=np.float64)
+        assert vec.shape == (self.dof, 2)
+        out = np.empty_like(vec)
+        _capi.check(_capi.lib().tm_smoother_apply(self._h, _capi.f64ptr(vec), _capi.f64ptr(out), 1 if scaled else 0))
+        return out
+
+    def rhs(self):
+        out = np.empty((self.dof, 2))
+        _capi.check(_capi.lib().tm_smoother_rhs(self._h, _capi.f64ptr(out)))
+        return out
+
+    def row_kinds(self):
+        out = np.empty(self.dof, dtype=np.int32)
+        _capi.check(_capi.lib().tm_smoother_row_kinds(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
+        return out
+
+    def profile(self, enable=True):
+        _capi.check(_capi.lib().tm_smoother_profile(self._h, 1 if enable else 0))
+
+    def profile_read(self):
+        """(milliseconds summed over K2 launches, number of K2 launches) since the last read."""
+        ms = C.c_double(0)
+        n = C.c_uint64(0)
+        _capi.check(_capi.lib().tm_smoother_profile_read(self._h, C.byref(ms), C.byref(n)))
+        return ms.value, int(n.value)
+
+    def control_function(self):
+        out = np.empty((self.dof, 2))
+        _capi.check(_capi.lib().tm_smoother_control_function(self._h, _capi.f64ptr(out)))
+        return out
+
+
+def plan_rows(mesh_data):
+    """Host-only: the perimeter-row table (tm_plan_build) as numpy arrays.  Works without a GPU."""
+    md = _capi.MeshDesc(mesh_data, with_coordinates=False)
+    rows = _capi.tm_plan_rows()
+    _capi.check(_capi.lib().tm_plan_build(md.ref(), C.byref(rows)))
+    try:
+        n = int(rows.nrows)
+        as_np = np.ctypeslib.as_array
+        out = {
+            "row": as_np(rows.row, (n,)).copy(), "kind": as_np(rows.kind, (n,)).copy(), "ncols": as_np(rows.ncols, (n,)).copy(),
+            "cols": as_np(rows.cols, (n * 9,)).reshape(n, 9).copy(), "coef_x": as_np(rows.coef_x, (n * 9,)).reshape(n, 9).copy(),
+            "coef_y": as_np(rows.coef_y, (n * 9,)).reshape(n, 9).copy(), "rhs": as_np(rows.rhs, (n * 2,)).reshape(n, 2).copy(),
+            "slot": as_np(rows.slot, (n * 9,)).reshape(n, 9).copy(),
+        }
+    finally:
+        _capi.lib().tm_plan_free(C.byref(rows))
+    return out
