@@ -197,17 +197,20 @@ def two_by_two(n, m=None, warp=0.04, tfi=None) -> Mesh:
 # hard-coded layout (blocks 0,1 walls at j = 0, connection 0 = {0,j_min,0..} <-> {1,j_min,0..};
 # wall_control_function.zig:72, 204-213)
 # ---------------------------------------------------------------------------------------------
-def plate(ni, nj, height=0.5, upstream=0.5, wall_cluster=None, tfi=None) -> Mesh:
+def plate(ni, nj, height=0.5, upstream=0.5, thickness=0.12, wall_cluster=None, tfi=None) -> Mesh:
+    """Round-nosed plate of finite thickness; sign = +1 upper block, -1 lower block (mirror image)."""
     s = cluster.Uniform().compute(ni)
     t = (wall_cluster or cluster.Uniform()).compute(nj)
     mesh = Mesh()
     for sign in (1.0, -1.0):
-        wall = np.stack([s, np.zeros(ni)], axis=1)                                        # i_min edge (j = 0): the plate
+        yw = sign * thickness * np.sqrt(s) * (1.0 - 0.5 * s)
+        wall = np.stack([s, yw], axis=1)                                                   # i_min edge (j = 0): the wall
         ang = 0.5 * math.pi * (1.0 - s)
         outer = np.stack([1.0 - (1.0 + upstream) * np.sin(ang), sign * height * np.cos(ang) ** 0.5], axis=1)   # i_max edge
         outer[0], outer[-1] = (-upstream, 0.0), (1.0, sign * height)
         lead = np.stack([-upstream * t, np.zeros(nj)], axis=1)                            # j_min edge (i = 0): upstream line
-        trail = np.stack([np.ones(nj), sign * height * t], axis=1)                        # j_max edge (i = ni-1)
+        trail = np.stack([np.ones(nj), yw[-1] + (sign * height - yw[-1]) * t], axis=1)    # j_max edge (i = ni-1)
+        wall[0] = (0.0, 0.0)
         lead[0], lead[-1] = wall[0], outer[0]
         trail[0], trail[-1] = wall[-1], outer[-1]
         mesh.addBlock("up" if sign > 0 else "down", _seed(Edge(wall, s), Edge(outer, s.copy()), Edge(lead, t), Edge(trail, t.copy()), tfi))
