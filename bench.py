@@ -67,6 +67,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--rows", type=int, default=0, help="K2 rows per chunk (tuning)")
     ap.add_argument("--unroll", type=int, default=0, help="K2 row unroll (tuning)")
+    ap.add_argument("--pipe", type=int, default=-1, help="K2 software pipelining 0/1 (tuning)")
+    ap.add_argument("--nt", type=int, default=-1, help="K2 non-temporal stores 0/1 (tuning)")
     args = ap.parse_args()
 
     import numpy as np
@@ -84,8 +86,8 @@ def main():
     from turbomesh_amd import _capi, configs
     from turbomesh_amd.smoothing import smooth, solver
 
-    if args.rows or args.unroll:
-        _capi.lib().tm_tune_apply(args.rows, args.unroll)
+    if args.rows or args.unroll or args.pipe >= 0 or args.nt >= 0:
+        _capi.lib().tm_tune_apply(args.rows, args.unroll, args.pipe, args.nt)
 
     n = args.n
     dist = None

@@ -230,6 +230,26 @@ typedef struct tm_plan_rows {
 int tm_plan_build(const tm_mesh_desc* mesh, tm_plan_rows* out);
 void tm_plan_free(tm_plan_rows* rows);
 
+/* Rank-local view of a partitioned mesh (host-only): which rows a rank owns, which remote rows it reads
+ * (ghost rows, appended after the owned rows in every rank-local vector) and the halo exchange lists.
+ * Every rank computes the same tables from the global topology, so no set-up communication is needed. */
+typedef struct tm_plan_local_info {
+    int64_t n_owned, n_ghost, n_send;
+    int32_t npeers, nowned_blocks;
+    int64_t* owned_blocks;   /* [nowned_blocks] global block ids, ascending                      */
+    int64_t* local_start;    /* [nowned_blocks] rank-local index of node (0,0) of each of them   */
+    int64_t* ghost_gid;      /* [n_ghost] global row ids, grouped by owner rank then ascending   */
+    int32_t* send_ids;       /* [n_send] rank-local indices of the rows packed for the peers     */
+    int64_t* send_gid;       /* [n_send] their global row ids                                    */
+    int32_t* peer_rank;      /* [npeers]                                                         */
+    int64_t* send_offset;    /* [npeers] rows; peer k gets send_ids[send_offset[k] .. +send_count[k]) */
+    int64_t* send_count;
+    int64_t* recv_offset;    /* [npeers] rows into the ghost segment                             */
+    int64_t* recv_count;
+} tm_plan_local_info;
+int tm_plan_local(const tm_mesh_desc* mesh, const int32_t* owner, int32_t rank, int32_t nranks, tm_plan_local_info* out);
+void tm_plan_local_free(tm_plan_local_info* info);
+
 /* ------------------------------------------------------------------ device-level entry points
  * Same kernels on caller-provided DEVICE pointers and stream, for callers that keep blocks in
  * HBM (bench.py, the multi-GPU driver).  No allocation, no synchronisation. */

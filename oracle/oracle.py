@@ -121,6 +121,7 @@ def lib():
         L.orc_system_matvec.restype = None
         L.orc_time_bicgstab_iterations.restype = C.c_double
         L.orc_time_bicgstab_iterations.argtypes = [C.c_uint64, C.c_uint64, _dp, C.c_uint64, _dp]
+        L.orc_mirror_apply_block.argtypes = [C.c_int, C.c_uint64, C.c_uint64, _dp, _dp, _dp, _dp, C.c_double]
         L.orc_time_relax_sweeps.restype = C.c_double
         L.orc_time_relax_sweeps.argtypes = [C.c_uint64, C.c_uint64, _dp, _dp, C.c_uint64, C.c_double]
         _lib = L
@@ -430,6 +431,23 @@ def time_bicgstab_iterations(xy, iters):
     t = lib().orc_time_bicgstab_iterations(C.c_uint64(xy.shape[0]), C.c_uint64(xy.shape[1]), xy.ctypes.data_as(_dp),
                                            C.c_uint64(iters), C.byref(fill))
     return float(t), fill.value
+
+
+MIRROR_RAW, MIRROR_SCALED, MIRROR_RESID, MIRROR_RELAX = 0, 1, 2, 3
+
+
+def mirror_apply_block(mode, vec, xk, pq=None, omega=1.0, out=None):
+    """Interior rows of one (ni, nj, 2) block in the DEVICE operation order (orc_mirror.cpp); perimeter of out untouched."""
+    vec, vp = _f64(vec)
+    xk, xp = _f64(xk)
+    pqa = None
+    pqp = None
+    if pq is not None:
+        pqa, pqp = _f64(pq)
+    if out is None:
+        out = np.zeros_like(vec)
+    _check(lib().orc_mirror_apply_block(mode, C.c_uint64(vec.shape[0]), C.c_uint64(vec.shape[1]), vp, xp, pqp, out.ctypes.data_as(_dp), C.c_double(omega)))
+    return out
 
 
 def time_relax_sweeps(xy, sweeps, omega=1.0):

@@ -242,47 +242,4 @@ double orc_time_bicgstab_iterations(uint64_t ni, uint64_t nj, double* xy, uint64
     return std::chrono::duration<double>(t3 - t2).count();
 }
 
-// Matrix-free Jacobi elliptic sweep: X' = X - omega * (A(X) X) / diag, interior nodes only,
-// boundary nodes copied.  Same per-node arithmetic (StencilData.init + 9-term row sum in CSR
-// column order) as one fill + mat-vec row of the reference.
-double orc_time_relax_sweeps(uint64_t ni, uint64_t nj, double* xy, double* scratch, uint64_t sweeps, double omega) {
-    using clk = std::chrono::steady_clock;
-    Vec2d* a = reinterpret_cast<Vec2d*>(xy);
-    Vec2d* b = reinterpret_cast<Vec2d*>(scratch);
-    auto t0 = clk::now();
-    for (uint64_t s = 0; s < sweeps; ++s) {
-        for (Index i = 0; i < ni; ++i)
-            for (Index j = 0; j < nj; ++j) {
-                const Index p = i * nj + j;
-                if (i == 0 || j == 0 || i == ni - 1 || j == nj - 1) {
-                    b[p] = a[p];
-                    continue;
-                }
-                const StencilData st = StencilData::init(a[p - nj], a[p + nj], a[p - 1], a[p + 1], 0.0, 0.0);
-                Vec2d r;
-                for (int c = 0; c < 2; ++c) {
-                    Float sum = 0.0;
-                    sum += st.get(StencilData::im1_jm1) * a[p - nj - 1].data[c];
-                    sum += st.get(StencilData::im1_j) * a[p - nj].data[c];
-                    sum += st.get(StencilData::im1_jp1) * a[p - nj + 1].data[c];
-                    sum += st.get(StencilData::i_jm1) * a[p - 1].data[c];
-                    sum += st.get(StencilData::i_j) * a[p].data[c];
-                    sum += st.get(StencilData::i_jp1) * a[p + 1].data[c];
-                    sum += st.get(StencilData::ip1_jm1) * a[p + nj - 1].data[c];
-                    sum += st.get(StencilData::ip1_j) * a[p + nj].data[c];
-                    sum += st.get(StencilData::ip1_jp1) * a[p + nj + 1].data[c];
-                    // same expression as the HIP relax sweep: in + omega * (rhs*dinv - sum*dinv), rhs = 0
-                    const Float diag = st.get(StencilData::i_j);
-                    const Float dinv = (diag == 0.0) ? 1.0 : 1.0 / diag;
-                    r.data[c] = a[p].data[c] + omega * (0.0 * dinv - sum * dinv);
-                }
-                b[p] = r;
-            }
-        std::swap(a, b);
-    }
-    auto t1 = clk::now();
-    if (sweeps % 2 == 1) std::memcpy(xy, scratch, sizeof(Vec2d) * ni * nj);
-    return std::chrono::duration<double>(t1 - t0).count();
-}
-
 }  // extern "C"

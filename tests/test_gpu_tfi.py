@@ -15,6 +15,8 @@ pytestmark = pytest.mark.gpu
 
 def _curved_edges(ni, nj, cl_i1, cl_i2, cl_j1, cl_j2):
     s1, s2, t1, t2 = cl_i1.compute(ni), cl_i2.compute(ni), cl_j1.compute(nj), cl_j2.compute(nj)
+    for c in (s1, s2, t1, t2):   # the reference asserts first == 0 and last == 1.0 exactly (tfi.zig:135-145)
+        c[0], c[-1] = 0.0, 1.0
     i_min = np.stack([s1 * 2.0, 0.15 * np.sin(math.pi * s1)], axis=1)
     i_max = np.stack([s2 * 2.0 + 0.1 * np.sin(math.pi * s2), 1.0 + 0.2 * np.sin(2 * math.pi * s2)], axis=1)
     j_min = np.stack([-0.1 * np.sin(math.pi * t1), t1], axis=1)

@@ -12,7 +12,7 @@ import os
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libtm_hip.so")
+LIB_PATH = os.environ.get("TM_HIP_LIB") or os.path.join(_HERE, "libtm_hip.so")   # TM_HIP_LIB: experiment builds only
 
 # tm_error
 TM_OK, TM_W_NOT_CONVERGED = 0, 1
@@ -87,12 +87,20 @@ class tm_plan_rows(C.Structure):
                 ("rhs", C.POINTER(C.c_double)), ("slot", C.POINTER(C.c_int32))]
 
 
+class tm_plan_local_info(C.Structure):
+    _fields_ = [("n_owned", C.c_int64), ("n_ghost", C.c_int64), ("n_send", C.c_int64), ("npeers", C.c_int32), ("nowned_blocks", C.c_int32),
+                ("owned_blocks", C.POINTER(C.c_int64)), ("local_start", C.POINTER(C.c_int64)), ("ghost_gid", C.POINTER(C.c_int64)),
+                ("send_ids", C.POINTER(C.c_int32)), ("send_gid", C.POINTER(C.c_int64)), ("peer_rank", C.POINTER(C.c_int32)),
+                ("send_offset", C.POINTER(C.c_int64)), ("send_count", C.POINTER(C.c_int64)), ("recv_offset", C.POINTER(C.c_int64)),
+                ("recv_count", C.POINTER(C.c_int64))]
+
+
 # every symbol include/tm_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
     "tm_last_error", "tm_abi_version", "tm_tfi_block", "tm_tfi_linear2d", "tm_smooth_mesh", "tm_smoother_create",
     "tm_smoother_workspace_bytes", "tm_smoother_iterate", "tm_smoother_download", "tm_smoother_upload", "tm_smoother_destroy",
     "tm_smoother_exchange_plan", "tm_smoother_apply", "tm_smoother_rhs", "tm_smoother_row_kinds", "tm_smoother_dof",
-    "tm_smoother_control_function", "tm_smoother_profile", "tm_smoother_profile_read", "tm_plan_build", "tm_plan_free", "tm_dev_tfi_block", "tm_dev_relax_sweep",
+    "tm_smoother_control_function", "tm_smoother_profile", "tm_smoother_profile_read", "tm_plan_build", "tm_plan_free", "tm_plan_local", "tm_plan_local_free", "tm_dev_tfi_block", "tm_dev_relax_sweep",
     "tm_dev_relax_partials_needed",
 ]
 
@@ -135,10 +143,14 @@ def lib():
         L.tm_plan_build.argtypes = [C.POINTER(tm_mesh_desc), C.POINTER(tm_plan_rows)]
         L.tm_plan_free.argtypes = [C.POINTER(tm_plan_rows)]
         L.tm_plan_free.restype = None
+        L.tm_plan_local.argtypes = [C.POINTER(tm_mesh_desc), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(tm_plan_local_info)]
+        L.tm_plan_local_free.argtypes = [C.POINTER(tm_plan_local_info)]
+        L.tm_plan_local_free.restype = None
         L.tm_dev_tfi_block.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 8 + [C.c_void_p]
         L.tm_dev_relax_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_void_p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.c_void_p]
-        L.tm_tune_apply.argtypes = [C.c_int, C.c_int]
+        L.tm_diag_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+        L.tm_tune_apply.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
 
@@ -161,7 +173,7 @@ class MeshDesc:
         self._blocks = (tm_block * max(1, len(blocks)))()
         for k, b in enumerate(blocks):
             data = b.points.data
-            if with_coordinates:
+            if with_coordinates and data is not None:
                 if data.dtype != np.float64 or not data.flags["C_CONTIGUOUS"]:
                     raise TmError(TM_E_ARG, "block coordinates must be C-contiguous float64")
                 self._blocks[k] = tm_block(f64ptr(data), b.points.size[0], b.points.size[1])

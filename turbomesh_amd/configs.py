@@ -73,11 +73,12 @@ def single_block(ni, nj=None, amplitude=0.1, tfi=None, perturb=0.0, seed=12345) 
 # ---------------------------------------------------------------------------------------------
 # config 4: strip of blocks stacked in the i direction (i <-> y, j <-> x), one interface per pair
 # ---------------------------------------------------------------------------------------------
-def strip(nblocks, ni, nj=None, amplitude=0.1, tfi=None, reverse_odd=False) -> Mesh:
+def strip(nblocks, ni, nj=None, amplitude=0.1, tfi=None, reverse_odd=False, only_blocks=None) -> Mesh:
     """Block k: j_min edge (i = 0) = C_k, j_max edge (i = ni-1) = C_{k+1},
     C_k(t) = (t, k + A (1 - 2k/nblocks) sin 2 pi t).  Connections
     {k, j_max, 0, nj-1} <-> {k+1, j_min, 0, nj-1}.  reverse_odd flips the j direction of odd blocks
-    (their ranges then run nj-1 -> 0) to exercise reversed connections."""
+    (their ranges then run nj-1 -> 0) to exercise reversed connections.  only_blocks: build coordinates only for
+    these block ids (the blocks a rank owns); the others are size-only placeholders."""
     nj = nj or ni
     t = cluster.Uniform().compute(nj)
     s = cluster.Uniform().compute(ni)
@@ -87,9 +88,12 @@ def strip(nblocks, ni, nj=None, amplitude=0.1, tfi=None, reverse_odd=False) -> M
         c[0], c[-1] = (0.0, float(k)), (1.0, float(k))
         return c
 
-    curves = [curve(k) for k in range(nblocks + 1)]
+    curves = {k: curve(k) for k in range(nblocks + 1) if only_blocks is None or k in only_blocks or (k - 1) in only_blocks}
     m = Mesh()
     for k in range(nblocks):
+        if only_blocks is not None and k not in only_blocks:
+            m.addBlock(f"block_{k}", Block2d(Mat2d.placeholder((ni, nj))))
+            continue
         left = np.stack([np.zeros(ni), k + s], axis=1)       # x = 0
         right = np.stack([np.ones(ni), k + s], axis=1)       # x = 1
         left[0], left[-1] = curves[k][0], curves[k + 1][0]

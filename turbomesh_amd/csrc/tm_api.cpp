@@ -57,15 +57,65 @@ struct DevBuf {
 
 static bool close2(const double* a, const double* b, double tol) { return std::fabs(a[0] - b[0]) <= tol && std::fabs(a[1] - b[1]) <= tol; }
 
+static Topology topo_of(const tm_mesh_desc* mesh) {
+    Topology t;
+    if (!mesh || !mesh->blocks || mesh->nblocks == 0) throw TmError(TM_E_ARG, "mesh description without blocks");
+    for (uint64_t b = 0; b < mesh->nblocks; ++b) {
+        t.ni.push_back(static_cast<int64_t>(mesh->blocks[b].ni));
+        t.nj.push_back(static_cast<int64_t>(mesh->blocks[b].nj));
+    }
+    auto rng = [](const tm_range& r) {
+        return TopoRange{static_cast<int64_t>(r.block), r.side, static_cast<int64_t>(r.start), static_cast<int64_t>(r.end)};
+    };
+    for (uint64_t c = 0; c < mesh->nconns; ++c) {
+        TopoConn tc;
+        tc.r[0] = rng(mesh->conns[c].r[0]);
+        tc.r[1] = rng(mesh->conns[c].r[1]);
+        tc.periodic = mesh->conns[c].has_periodicity != 0;
+        tc.per[0] = mesh->conns[c].periodicity[0];
+        tc.per[1] = mesh->conns[c].periodicity[1];
+        t.conns.push_back(tc);
+    }
+    for (uint64_t c = 0; c < mesh->nbcs; ++c) t.bcs.push_back(TopoCond{rng(mesh->bcs[c].range), mesh->bcs[c].kind});
+    t.finalize();
+    return t;
+}
+
+template <class T>
+static T* dup(const std::vector<T>& v) {
+    T* p = static_cast<T*>(std::malloc(sizeof(T) * (v.empty() ? 1 : v.size())));
+    if (!p) throw TmError(TM_E_MEMORY, "out of host memory");
+    if (!v.empty()) std::memcpy(p, v.data(), sizeof(T) * v.size());
+    return p;
+}
+
 extern "C" {
 
 const char* tm_last_error(void) { return g_last_error.c_str(); }
 int tm_abi_version(void) { return TM_HIP_ABI_VERSION; }
 
 // internal tuning knob used by the benchmark sweeps (not part of the drop-in surface)
-int tm_tune_apply(int rows_per_chunk, int unroll) {
-    tune_apply(rows_per_chunk, unroll);
+int tm_tune_apply(int rows_per_chunk, int unroll, int pipe, int nt) {
+    tune_apply(rows_per_chunk, unroll, pipe, nt);
     return TM_OK;
+}
+
+// diagnostic: K2 with the same tiling / data movement but reduced arithmetic (mode 4 = copy, 5 = 9-point sum)
+int tm_diag_apply(const double* d_in, double* d_out, uint64_t ni, uint64_t nj, int mode, void* stream) {
+    return guarded([&]() {
+        ApplyBlock a;
+        a.in = reinterpret_cast<const double2*>(d_in);
+        a.xk = a.in;
+        a.pq = nullptr;
+        a.aux = nullptr;
+        a.out = reinterpret_cast<double2*>(d_out);
+        a.ni = static_cast<int>(ni);
+        a.nj = static_cast<int>(nj);
+        a.omega = 1.0;
+        a.partials = nullptr;
+        HIPCHK(launch_apply_block(a, mode, DOT_NONE, static_cast<hipStream_t>(stream)));
+        return TM_OK;
+    });
 }
 
 // ------------------------------------------------------------------ TFI (tfi.zig:112-208)
@@ -299,30 +349,58 @@ int tm_smooth_mesh(const tm_mesh_desc* mesh, uint64_t iterations, const tm_solve
 }
 
 // ------------------------------------------------------------------ host-only planning export
+int tm_plan_local(const tm_mesh_desc* mesh, const int32_t* owner, int32_t rank, int32_t nranks, tm_plan_local_info* out) {
+    return guarded([&]() {
+        if (!mesh || !owner || !out) throw TmError(TM_E_ARG, "null argument");
+        std::memset(out, 0, sizeof(*out));
+        const Topology t = topo_of(mesh);
+        const std::vector<PlanRow> rows = build_rows(t);
+        const std::vector<int32_t> own(owner, owner + t.nblocks());
+        const LocalPlan lp = build_local_plan(t, rows, own, rank, nranks);
+        out->n_owned = lp.n_owned;
+        out->n_ghost = static_cast<int64_t>(lp.ghost_gid.size());
+        out->n_send = static_cast<int64_t>(lp.send_ids.size());
+        out->npeers = static_cast<int32_t>(lp.peer_rank.size());
+        out->nowned_blocks = static_cast<int32_t>(lp.owned_blocks.size());
+        std::vector<int64_t> send_gid;
+        for (int32_t l : lp.send_ids) {
+            size_t k = lp.owned_blocks.size() - 1;
+            while (l < lp.local_start[k]) --k;
+            send_gid.push_back(t.start[lp.owned_blocks[k]] + (l - lp.local_start[k]));
+        }
+        out->owned_blocks = dup(lp.owned_blocks);
+        out->local_start = dup(lp.local_start);
+        out->ghost_gid = dup(lp.ghost_gid);
+        out->send_ids = dup(lp.send_ids);
+        out->send_gid = dup(send_gid);
+        out->peer_rank = dup(lp.peer_rank);
+        out->send_offset = dup(lp.send_off);
+        out->send_count = dup(lp.send_cnt);
+        out->recv_offset = dup(lp.recv_off);
+        out->recv_count = dup(lp.recv_cnt);
+        return TM_OK;
+    });
+}
+void tm_plan_local_free(tm_plan_local_info* i) {
+    if (!i) return;
+    std::free(i->owned_blocks);
+    std::free(i->local_start);
+    std::free(i->ghost_gid);
+    std::free(i->send_ids);
+    std::free(i->send_gid);
+    std::free(i->peer_rank);
+    std::free(i->send_offset);
+    std::free(i->send_count);
+    std::free(i->recv_offset);
+    std::free(i->recv_count);
+    std::memset(i, 0, sizeof(*i));
+}
+
 int tm_plan_build(const tm_mesh_desc* mesh, tm_plan_rows* out) {
     return guarded([&]() {
         if (!mesh || !out) throw TmError(TM_E_ARG, "null argument");
         std::memset(out, 0, sizeof(*out));
-        Topology t;
-        if (!mesh->blocks || mesh->nblocks == 0) throw TmError(TM_E_ARG, "mesh description without blocks");
-        for (uint64_t b = 0; b < mesh->nblocks; ++b) {
-            t.ni.push_back(static_cast<int64_t>(mesh->blocks[b].ni));
-            t.nj.push_back(static_cast<int64_t>(mesh->blocks[b].nj));
-        }
-        auto rng = [](const tm_range& r) {
-            return TopoRange{static_cast<int64_t>(r.block), r.side, static_cast<int64_t>(r.start), static_cast<int64_t>(r.end)};
-        };
-        for (uint64_t c = 0; c < mesh->nconns; ++c) {
-            TopoConn tc;
-            tc.r[0] = rng(mesh->conns[c].r[0]);
-            tc.r[1] = rng(mesh->conns[c].r[1]);
-            tc.periodic = mesh->conns[c].has_periodicity != 0;
-            tc.per[0] = mesh->conns[c].periodicity[0];
-            tc.per[1] = mesh->conns[c].periodicity[1];
-            t.conns.push_back(tc);
-        }
-        for (uint64_t c = 0; c < mesh->nbcs; ++c) t.bcs.push_back(TopoCond{rng(mesh->bcs[c].range), mesh->bcs[c].kind});
-        t.finalize();
+        const Topology t = topo_of(mesh);
         const std::vector<PlanRow> rows = build_rows(t);
         const size_t n = rows.size();
         out->nrows = n;

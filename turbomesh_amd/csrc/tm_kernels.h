@@ -12,7 +12,10 @@ enum ApplyMode : int {
     MODE_RAW = 0,      // out = sum
     MODE_SCALED = 1,   // out = sum * dinv                      (D^-1 A in)
     MODE_RESID = 2,    // out = rhs*dinv - sum*dinv             (D^-1 (b - A in)), rhs = 0 on interior rows
-    MODE_RELAX = 3     // out = in + omega * (rhs*dinv - sum*dinv)
+    MODE_RELAX = 3,    // out = in + omega * (rhs*dinv - sum*dinv)
+    // diagnostics (tools/tune_k2.py only): same tiling and data movement, reduced arithmetic
+    MODE_DIAG_COPY = 4,   // out = in
+    MODE_DIAG_SUM9 = 5    // out = plain sum of the 9 neighbours (loads, halo, lane shifts; no coefficients)
 };
 // ---- fused partial reductions written per workgroup (x and y components separately)
 enum DotMode : int {
@@ -36,7 +39,7 @@ struct ApplyBlock {
 };
 // number of workgroups k2 launches for a block (also the number of partial rows it writes)
 int apply_block_nwg(int ni, int nj);
-void tune_apply(int rows_per_chunk, int unroll);   // <=0 keeps the current value
+void tune_apply(int rows_per_chunk, int unroll, int pipe, int nt);   // <=0 (pipe, nt: <0) keeps the current value
 hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_t stream);
 
 // ---- K4/K5 perimeter rows (device SoA, built on the host by tm_plan)
@@ -45,7 +48,8 @@ struct EdgeRowsDev {
     const int32_t* row = nullptr;       // [nrows] local vector index of the row
     const int8_t* kind = nullptr;       // [nrows] BlockBoundaryPointKind
     const int8_t* ncols = nullptr;      // [nrows]
-    const int32_t* cols = nullptr;      // [nrows*9] local vector indices, ascending GLOBAL id order
+    // per-column arrays are stored TRANSPOSED ([9][nrows], [4][nrows]) so that a wave reads them coalesced
+    const int32_t* cols = nullptr;      // [9*nrows] local vector indices, ascending GLOBAL id order
     const double* cx = nullptr;         // [nrows*9] static x-system coefficients
     const double* cy = nullptr;         // [nrows*9] static y-system coefficients
     const int8_t* slot = nullptr;       // [nrows*9] smoothed rows: stencil slot per column

@@ -1,9 +1,12 @@
 // gfx950 (MI355X, CDNA4) kernels of the structured-grid smoother.  HIP only, wave64 only.
 //
 // All arithmetic is fp64 and HBM-bandwidth bound (about 2 flop/B): no MFMA.  The file is built
-// with -ffp-contract=off so every a*b+c is evaluated exactly like the reference's Zig code
-// (strict IEEE, no fused multiply-add); the operator and TFI kernels then reproduce the CPU
-// oracle bit for bit, only the reductions (tree order) differ.
+// with -ffp-contract=off: the compiler never fuses a*b+c on its own, so TFI (K1) and the
+// perimeter rows (K4/K5) evaluate exactly the reference's strict-IEEE Zig expressions and match
+// the CPU oracle bit for bit.  The interior rows (K2) use an algebraically factored form with
+// EXPLICIT fma() calls (half the fp64 work of the term-by-term sum); the oracle mirrors that
+// sequence (oracle/orc_mirror.cpp), so K2 is bit-exact against the mirror and within rounding
+// (tolerance in the tests) of the reference's CSR mat-vec.  Reductions differ by tree order.
 //
 // K2 design (the dominant kernel).  A workgroup is 4 waves side by side; wave w owns the 64
 // columns [j0, j0+64) of a 256-column strip and MARCHES down a chunk of rows, keeping a
@@ -16,7 +19,9 @@
 //   - no LDS tile, no barrier in the row loop, so the four waves stay independent and the
 //     loads of U rows are in flight together;
 //   - Jacobi scaling, the relaxation update and the partial dot products are fused into the
-//     same pass, so one sweep moves the compulsory 32 B/node (field mode, Laplace).
+//     same pass, so one sweep moves the compulsory 32 B/node (field mode, Laplace);
+//   - results are written with non-temporal stores: the output is not re-read before the next
+//     sweep, and keeping it out of L2 is worth ~25 % on a streaming copy of this footprint.
 // Workgroup ids are remapped so that every XCD (own L2) walks a contiguous range of
 // (row-chunk, strip) tiles: the halo lines shared by neighbouring tiles hit in that L2.
 #include "tm_kernels.h"
@@ -133,13 +138,68 @@ __device__ __forceinline__ void accumulate(double (&acc)[MAX_PARTIALS], double2 
 }
 
 // ------------------------------------------------------------------------------------------
-// K2  winslow_apply: interior rows of one block (replaces smooth.zig:923-992 fill +
-//     BiCGStab.zig:424-435 mat-vec; row sum in the CSR column order of smooth.zig:494-502)
+// Interior row in FACTORED form.  With the unscaled central differences
+//     d_xi = X(i+1,j) - X(i-1,j),  d_eta = X(i,j+1) - X(i,j-1)          (= 2 x_xi, 2 x_eta)
+//     G11 = d_xi.d_xi = 4 g11,  G22 = d_eta.d_eta = 4 g22,  G12 = d_xi.d_eta = 4 g12
+// the reference's row  sum = sum_k c_k w_k  (coefficients of smooth.zig:171-216) is
+//   4 sum = G22 [ (w_p + w_m) + P/2 (w_p - w_m) ] + G11 [ (w_r + w_l) + Q/2 (w_r - w_l) ]
+//           - 2 (G11 + G22) w_c - G12/2 [ (w_pp + w_mm) - (w_pm + w_mp) ],      4 a_ii = -2 (G11 + G22)
+// (m/c/p = rows i-1/i/i+1, l/r = columns j-1/j+1).  About half the fp64 operations of the
+// term-by-term CSR sum; same real-arithmetic value, rounding differs at the 1e-16 level, so
+// interior rows are compared with the faithful CSR mat-vec by tolerance and BIT-EXACTLY with the
+// oracle's mirror of this very sequence (oracle/orc_mirror.cpp): every fma below is explicit,
+// everything else is built with -ffp-contract=off.
 // ------------------------------------------------------------------------------------------
-static int g_rows_per_chunk = 64;   // tunable (tm_tune)
-static int g_unroll = 4;
+template <int MODE, bool HAS_PQ>
+__device__ __forceinline__ double2 winslow_row(double2 m_l, double2 m_c, double2 m_r, double2 c_l, double2 c_c, double2 c_r, double2 p_l,
+                                               double2 p_c, double2 p_r, double2 xm, double2 xp, double2 xl, double2 xr, double P, double Q,
+                                               double omega) {
+    const double dxi_x = xp.x - xm.x, dxi_y = xp.y - xm.y;
+    const double det_x = xr.x - xl.x, det_y = xr.y - xl.y;
+    const double G11 = fma(dxi_x, dxi_x, dxi_y * dxi_y);
+    const double G22 = fma(det_x, det_x, det_y * det_y);
+    const double G12 = fma(dxi_x, det_x, dxi_y * det_y);
+    const double D = G11 + G22;
+    const double m2D = -2.0 * D;      // 4 a_ii
+    const double mhG12 = -0.5 * G12;
+    double ax = p_c.x + m_c.x, ay = p_c.y + m_c.y;
+    double bx = c_r.x + c_l.x, by = c_r.y + c_l.y;
+    if (HAS_PQ) {
+        const double hP = 0.5 * P, hQ = 0.5 * Q;
+        ax = fma(hP, p_c.x - m_c.x, ax);
+        ay = fma(hP, p_c.y - m_c.y, ay);
+        bx = fma(hQ, c_r.x - c_l.x, bx);
+        by = fma(hQ, c_r.y - c_l.y, by);
+    }
+    const double kx = (p_r.x + m_l.x) - (p_l.x + m_r.x);
+    const double ky = (p_r.y + m_l.y) - (p_l.y + m_r.y);
+    double sx = G22 * ax, sy = G22 * ay;
+    sx = fma(G11, bx, sx);
+    sy = fma(G11, by, sy);
+    sx = fma(m2D, c_c.x, sx);
+    sy = fma(m2D, c_c.y, sy);
+    sx = fma(mhG12, kx, sx);
+    sy = fma(mhG12, ky, sy);   // sx, sy = 4 * (A w)_row
+    if (MODE == MODE_RAW) return make_double2(0.25 * sx, 0.25 * sy);
+    const double rinv = (D == 0.0) ? 0.25 : 1.0 / m2D;   // 1 / (4 a_ii); a_ii == 0 -> D^-1 := 1 (BiCGStab.zig:169-173)
+    const double tx = sx * rinv, ty = sy * rinv;          // (D^-1 A w)_row
+    if (MODE == MODE_SCALED) return make_double2(tx, ty);
+    if (MODE == MODE_RESID) return make_double2(-tx, -ty);   // b = 0 on interior rows
+    return make_double2(fma(omega, -tx, c_c.x), fma(omega, -ty, c_c.y));   // MODE_RELAX
+}
 
-template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U>
+// ------------------------------------------------------------------------------------------
+// K2  winslow_apply: interior rows of one block (replaces smooth.zig:923-992 fill +
+//     BiCGStab.zig:424-435 mat-vec), matrix-free, factored row evaluation (winslow_row)
+// ------------------------------------------------------------------------------------------
+static int g_rows_per_chunk = 64;   // tunable (tm_tune_apply)
+static int g_unroll = 2;
+static int g_pipe = 1;
+static int g_nt = 0;
+
+typedef double d2v __attribute__((ext_vector_type(2)));
+
+template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool PIPE, bool NT>
 __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, int nRC) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -187,55 +247,83 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
             xc_r = lane_next(t_h, xc_c);
         }
 
-        for (int ib = i0; ib < i1; ib += U) {
+        struct Group {
             double2 pc[U], ph[U], xpc[U], xph[U], pqv[U], auxv[U];
+        };
+        auto load_group = [&](int ib, Group& g) {   // rows ib+1 .. ib+U of the vector (and of xk), pq/aux of rows ib .. ib+U-1
 #pragma unroll
-            for (int u = 0; u < U; ++u) {   // issue all loads of the group first
+            for (int u = 0; u < U; ++u) {
                 const int prow = min(ib + u + 1, ni - 1);
-                load_row(a.in, prow, pc[u], ph[u]);
-                if (!FIELD) load_row(a.xk, prow, xpc[u], xph[u]);
+                load_row(a.in, prow, g.pc[u], g.ph[u]);
+                if (!FIELD) load_row(a.xk, prow, g.xpc[u], g.xph[u]);
                 const size_t cur = static_cast<size_t>(min(ib + u, ni - 2)) * nj + jc;
-                if (HAS_PQ) pqv[u] = a.pq[cur];
-                if (DOT == DOT_AUX) auxv[u] = a.aux[cur];
+                if (HAS_PQ) g.pqv[u] = a.pq[cur];
+                if (DOT == DOT_AUX) g.auxv[u] = a.aux[cur];
             }
+        };
+        auto compute_group = [&](int ib, const Group& g) {
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int row = ib + u;
-                const double2 wp_c = pc[u];
-                const double2 wp_l = lane_prev(ph[u], pc[u]), wp_r = lane_next(ph[u], pc[u]);
+                const double2 wp_c = g.pc[u];
+                const double2 wp_l = lane_prev(g.ph[u], g.pc[u]), wp_r = lane_next(g.ph[u], g.pc[u]);
 
-                double c[9];
-                const double P = HAS_PQ ? pqv[u].x : 0.0, Q = HAS_PQ ? pqv[u].y : 0.0;
-                if (FIELD) stencil_coefs<HAS_PQ>(wm_c, wp_c, wc_l, wc_r, P, Q, c);
-                else stencil_coefs<HAS_PQ>(xm_c, xpc[u], xc_l, xc_r, P, Q, c);
-
-                double sx = 0.0, sy = 0.0;   // CSR order: (i-1,j-1) (i-1,j) (i-1,j+1) (i,j-1) (i,j) (i,j+1) (i+1,j-1) (i+1,j) (i+1,j+1)
-                sx += c[S_IM1_JM1] * wm_l.x; sy += c[S_IM1_JM1] * wm_l.y;
-                sx += c[S_IM1_J] * wm_c.x;   sy += c[S_IM1_J] * wm_c.y;
-                sx += c[S_IM1_JP1] * wm_r.x; sy += c[S_IM1_JP1] * wm_r.y;
-                sx += c[S_I_JM1] * wc_l.x;   sy += c[S_I_JM1] * wc_l.y;
-                sx += c[S_I_J] * wc_c.x;     sy += c[S_I_J] * wc_c.y;
-                sx += c[S_I_JP1] * wc_r.x;   sy += c[S_I_JP1] * wc_r.y;
-                sx += c[S_IP1_JM1] * wp_l.x; sy += c[S_IP1_JM1] * wp_l.y;
-                sx += c[S_IP1_J] * wp_c.x;   sy += c[S_IP1_J] * wp_c.y;
-                sx += c[S_IP1_JP1] * wp_r.x; sy += c[S_IP1_JP1] * wp_r.y;
-
+                const double P = HAS_PQ ? g.pqv[u].x : 0.0, Q = HAS_PQ ? g.pqv[u].y : 0.0;
                 double2 o;
-                o.x = row_out<MODE>(sx, 0.0, c[S_I_J], wc_c.x, a.omega);
-                o.y = row_out<MODE>(sy, 0.0, c[S_I_J], wc_c.y, a.omega);
+                if (MODE == MODE_DIAG_COPY) {
+                    o = wc_c;
+                } else if (MODE == MODE_DIAG_SUM9) {
+                    o.x = wm_l.x + wm_c.x + wm_r.x + wc_l.x + wc_c.x + wc_r.x + wp_l.x + wp_c.x + wp_r.x;
+                    o.y = wm_l.y + wm_c.y + wm_r.y + wc_l.y + wc_c.y + wc_r.y + wp_l.y + wp_c.y + wp_r.y;
+                } else if (FIELD) {
+                    o = winslow_row<MODE, HAS_PQ>(wm_l, wm_c, wm_r, wc_l, wc_c, wc_r, wp_l, wp_c, wp_r, wm_c, wp_c, wc_l, wc_r, P, Q, a.omega);
+                } else {
+                    o = winslow_row<MODE, HAS_PQ>(wm_l, wm_c, wm_r, wc_l, wc_c, wc_r, wp_l, wp_c, wp_r, xm_c, g.xpc[u], xc_l, xc_r, P, Q, a.omega);
+                }
                 if (row < i1 && valid_col) {
-                    a.out[static_cast<size_t>(row) * nj + j] = o;
-                    accumulate<DOT>(acc, wc_c, o, (DOT == DOT_AUX) ? auxv[u] : o);
+                    double2* dst = a.out + static_cast<size_t>(row) * nj + j;
+                    if (NT) {
+                        d2v ov;
+                        ov.x = o.x;
+                        ov.y = o.y;
+                        __builtin_nontemporal_store(ov, reinterpret_cast<d2v*>(dst));
+                    } else {
+                        *dst = o;
+                    }
+                    accumulate<DOT>(acc, wc_c, o, (DOT == DOT_AUX) ? g.auxv[u] : o);
                 }
                 // slide the window down one row
                 wm_c = wc_c; wm_l = wc_l; wm_r = wc_r;
                 wc_c = wp_c; wc_l = wp_l; wc_r = wp_r;
                 if (!FIELD) {
                     xm_c = xc_c;
-                    xc_c = xpc[u];
-                    xc_l = lane_prev(xph[u], xpc[u]);
-                    xc_r = lane_next(xph[u], xpc[u]);
+                    xc_c = g.xpc[u];
+                    xc_l = lane_prev(g.xph[u], g.xpc[u]);
+                    xc_r = lane_next(g.xph[u], g.xpc[u]);
                 }
+            }
+        };
+
+        if (PIPE) {   // software pipeline: the loads of the next row group are in flight while this one is computed
+            Group A, B;
+            int ib = i0;
+            load_group(ib, A);
+            while (true) {
+                const bool hasB = ib + U < i1;
+                if (hasB) load_group(ib + U, B);
+                compute_group(ib, A);
+                if (!hasB) break;
+                const bool hasA = ib + 2 * U < i1;
+                if (hasA) load_group(ib + 2 * U, A);
+                compute_group(ib + U, B);
+                if (!hasA) break;
+                ib += 2 * U;
+            }
+        } else {
+            for (int ib = i0; ib < i1; ib += U) {
+                Group g;
+                load_group(ib, g);
+                compute_group(ib, g);
             }
         }
     }
@@ -259,11 +347,21 @@ int apply_block_nwg(int ni, int nj) {
 template <int MODE, int DOT, bool FIELD, bool HAS_PQ>
 static hipError_t launch_apply_u(const ApplyBlock& a, int RI, int nSG, int nRC, hipStream_t st) {
     const dim3 grid(nSG * nRC), block(256);
-    switch (g_unroll) {
-        case 1: hipLaunchKernelGGL((k_apply<MODE, DOT, FIELD, HAS_PQ, 1>), grid, block, 0, st, a, RI, nSG, nRC); break;
-        case 2: hipLaunchKernelGGL((k_apply<MODE, DOT, FIELD, HAS_PQ, 2>), grid, block, 0, st, a, RI, nSG, nRC); break;
-        default: hipLaunchKernelGGL((k_apply<MODE, DOT, FIELD, HAS_PQ, 4>), grid, block, 0, st, a, RI, nSG, nRC); break;
+#define TM_K2(U_, P_, N_) hipLaunchKernelGGL((k_apply<MODE, DOT, FIELD, HAS_PQ, U_, P_, N_>), grid, block, 0, st, a, RI, nSG, nRC)
+    const int key = g_unroll * 100 + (g_pipe ? 10 : 0) + (g_nt ? 1 : 0);
+    switch (key) {
+        case 100: TM_K2(1, false, false); break;
+        case 110: TM_K2(1, true, false); break;
+        case 200: TM_K2(2, false, false); break;
+        case 201: TM_K2(2, false, true); break;
+        case 211: TM_K2(2, true, true); break;
+        case 400: TM_K2(4, false, false); break;
+        case 401: TM_K2(4, false, true); break;
+        case 410: TM_K2(4, true, false); break;
+        case 411: TM_K2(4, true, true); break;
+        default: TM_K2(2, true, false); break;   // 210
     }
+#undef TM_K2
     return hipGetLastError();
 }
 template <int MODE, int DOT>
@@ -290,12 +388,16 @@ hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_
     if (mode == MODE_RESID && dot == DOT_NONE) return launch_apply_md<MODE_RESID, DOT_NONE>(a, RI, nSG, nRC, st);
     if (mode == MODE_RELAX && dot == DOT_DELTA) return launch_apply_md<MODE_RELAX, DOT_DELTA>(a, RI, nSG, nRC, st);
     if (mode == MODE_RELAX && dot == DOT_NONE) return launch_apply_md<MODE_RELAX, DOT_NONE>(a, RI, nSG, nRC, st);
+    if (mode == MODE_DIAG_COPY) return launch_apply_md<MODE_DIAG_COPY, DOT_NONE>(a, RI, nSG, nRC, st);
+    if (mode == MODE_DIAG_SUM9) return launch_apply_md<MODE_DIAG_SUM9, DOT_NONE>(a, RI, nSG, nRC, st);
     return hipErrorInvalidValue;
 }
 
-void tune_apply(int rows, int unroll) {
+void tune_apply(int rows, int unroll, int pipe, int nt) {
     if (rows > 0) g_rows_per_chunk = rows;
     if (unroll == 1 || unroll == 2 || unroll == 4) g_unroll = unroll;
+    if (pipe >= 0) g_pipe = pipe;
+    if (nt >= 0) g_nt = nt;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -325,9 +427,8 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const d
         const int self = e.self[r];
         double sx = 0.0, sy = 0.0, rhs_x, rhs_y, diag_x, diag_y;
         if (kind == 1 /* smoothed */) {
-            const int32_t* m = e.metric + static_cast<size_t>(r) * 4;
-            const double2 im1_j = xk[m[0]], ip1_j = xk[m[1]], i_jm1 = xk[m[2]];
-            double2 i_jp1 = xk[m[3]];
+            const double2 im1_j = xk[e.metric[r]], ip1_j = xk[e.metric[e.nrows + r]], i_jm1 = xk[e.metric[2 * static_cast<size_t>(e.nrows) + r]];
+            double2 i_jp1 = xk[e.metric[3 * static_cast<size_t>(e.nrows) + r]];
             const bool periodic = e.flags[r] & 1;
             const double per_x = e.per[2 * r], per_y = e.per[2 * r + 1];
             if (periodic) {   // types.add(p, types.neg(periodicity)), smooth.zig:1032
@@ -341,8 +442,8 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const d
             stencil_coefs<true>(im1_j, ip1_j, i_jm1, i_jp1, P, Q, c);
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
-                const double ck = pick9(c, e.slot[static_cast<size_t>(r) * 9 + k]);
-                const double2 w = in[e.cols[static_cast<size_t>(r) * 9 + k]];
+                const double ck = pick9(c, e.slot[static_cast<size_t>(k) * e.nrows + r]);
+                const double2 w = in[e.cols[static_cast<size_t>(k) * e.nrows + r]];
                 sx += ck * w.x;
                 sy += ck * w.y;
             }
@@ -361,8 +462,8 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const d
 #pragma unroll
             for (int k = 0; k < 9; ++k) {
                 if (k < nc) {
-                    const double ax = e.cx[static_cast<size_t>(r) * 9 + k], ay = e.cy[static_cast<size_t>(r) * 9 + k];
-                    const double2 w = in[e.cols[static_cast<size_t>(r) * 9 + k]];
+                    const double ax = e.cx[static_cast<size_t>(k) * e.nrows + r], ay = e.cy[static_cast<size_t>(k) * e.nrows + r];
+                    const double2 w = in[e.cols[static_cast<size_t>(k) * e.nrows + r]];
                     sx += ax * w.x;
                     sy += ay * w.y;
                     if (k == self) {
@@ -417,9 +518,8 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rhs(EdgeRowsDev e, const do
         const int kind = e.kind[r];
         double rhs_x, rhs_y, diag_x, diag_y;
         if (kind == 1) {
-            const int32_t* m = e.metric + static_cast<size_t>(r) * 4;
-            const double2 im1_j = xk[m[0]], ip1_j = xk[m[1]], i_jm1 = xk[m[2]];
-            double2 i_jp1 = xk[m[3]];
+            const double2 im1_j = xk[e.metric[r]], ip1_j = xk[e.metric[e.nrows + r]], i_jm1 = xk[e.metric[2 * static_cast<size_t>(e.nrows) + r]];
+            double2 i_jp1 = xk[e.metric[3 * static_cast<size_t>(e.nrows) + r]];
             const bool periodic = e.flags[r] & 1;
             const double per_x = e.per[2 * r], per_y = e.per[2 * r + 1];
             if (periodic) {
@@ -436,8 +536,8 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rhs(EdgeRowsDev e, const do
             rhs_y = periodic ? per_y * cs : 0.0;
         } else {
             const int self = e.self[r];
-            diag_x = e.cx[static_cast<size_t>(r) * 9 + self];
-            diag_y = e.cy[static_cast<size_t>(r) * 9 + self];
+            diag_x = e.cx[static_cast<size_t>(self) * e.nrows + r];
+            diag_y = e.cy[static_cast<size_t>(self) * e.nrows + r];
             rhs_x = e.rhs[2 * r];
             rhs_y = e.rhs[2 * r + 1];
         }

@@ -198,14 +198,14 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         h_flags[k] = pr.flags;
         h_per[2 * k] = pr.per[0];
         h_per[2 * k + 1] = pr.per[1];
-        for (int q = 0; q < pr.ncols; ++q) {
-            h_cols[k * 9 + q] = loc(pr.col[q]);
-            h_cx[k * 9 + q] = pr.cx[q];
-            h_cy[k * 9 + q] = pr.cy[q];
-            h_slot[k * 9 + q] = pr.slot[q];
+        for (int q = 0; q < pr.ncols; ++q) {   // transposed: column q of all rows is contiguous
+            h_cols[q * nr + k] = loc(pr.col[q]);
+            h_cx[q * nr + k] = pr.cx[q];
+            h_cy[q * nr + k] = pr.cy[q];
+            h_slot[q * nr + k] = pr.slot[q];
         }
         if (pr.kind == KIND_SMOOTHED)
-            for (int q = 0; q < 4; ++q) h_metric[k * 4 + q] = loc(pr.metric[q]);
+            for (int q = 0; q < 4; ++q) h_metric[q * nr + k] = loc(pr.metric[q]);
     }
     h_rhs.assign(nr * 2, 0.0);
     auto up = [&](const void* src, uint64_t bytes) -> void* {
@@ -345,7 +345,7 @@ void Smoother::apply(const double2* in, double2* out, int mode, int dot, const d
         }
     }
     HIPCHK(launch_edge_rows(edge, in, xk, PQ, aux, out, omega, mode, dot, partials + static_cast<size_t>(poff_edge) * MAX_PARTIALS, stream));
-    if (dot != DOT_NONE) reduce(nwg_apply);
+    if (dot != DOT_NONE && dot != DOT_DELTA) reduce(nwg_apply);   // relax sweeps leave the per-workgroup partials; summed when read
 }
 
 void Smoother::white_launch(int update) {
@@ -454,6 +454,7 @@ void Smoother::relax_sweeps(uint64_t n, tm_stats& st) {
         outer_done += 1;
     }
     if (n) {
+        reduce(nwg_apply);   // partial sums of the LAST sweep -> sum (x_old - x_new)^2, sum (y_old - y_new)^2
         HIPCHK(hipMemcpyAsync(h_red, red, sizeof(double) * MAX_PARTIALS, hipMemcpyDeviceToHost, stream));
         sync();
         st.last_dx2 = h_red[0];

@@ -1,0 +1,174 @@
+"""Multi-GPU driver: one process per GPU, one (group of) block(s) per rank.
+
+The device solver loop lives in libtm_hip.so; a rank becomes part of a multi-GPU job through
+`tm_comm_hooks` (include/tm_hip.h): the library packs the interface / first-interior rows its peers
+need, calls `exchange`, and sums its reduction scalars with `allreduce_sum`.  This module implements
+the two hooks with torch.distributed -- backend "nccl" is RCCL on ROCm, point-to-point over xGMI --
+on views of ONE torch workspace tensor that backs every device buffer of the handle.
+
+Exchange per operator application: one grouped isend/irecv pair per neighbouring rank
+(rows are double2 = 16 B: 64 KiB per direction for a 4096-node interface); all-reduce: 4 doubles.
+Both are latency-bound, so they are enqueued asynchronously on the stream the kernels run on and
+never synchronise the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _capi, configs
+from .smoothing import smooth, solver as _solver
+
+
+def strip_for_rank(world, rank, ni, nj, blocks_per_rank=1):
+    """Strip workload (configs.strip) with coordinates only for the blocks this rank owns."""
+    nb = world * blocks_per_rank
+    owned = set(range(rank * blocks_per_rank, (rank + 1) * blocks_per_rank))
+    return configs.strip(nb, ni, nj, only_blocks=owned)
+
+
+def local_plan(mesh, owner, rank, world):
+    """Host-only (no GPU): the rank-local plan of tm_plan_local as numpy arrays."""
+    md = _capi.MeshDesc(mesh, with_coordinates=False)
+    info = _capi.tm_plan_local_info()
+    own = (C.c_int32 * len(owner))(*owner)
+    _capi.check(_capi.lib().tm_plan_local(md.ref(), own, rank, world, C.byref(info)))
+    try:
+        def arr(ptr, n):
+            return np.ctypeslib.as_array(ptr, (n,)).copy() if n else np.zeros(0, dtype=np.int64)
+
+        return {
+            "n_owned": int(info.n_owned), "n_ghost": int(info.n_ghost), "n_send": int(info.n_send),
+            "owned_blocks": arr(info.owned_blocks, info.nowned_blocks), "local_start": arr(info.local_start, info.nowned_blocks),
+            "ghost_gid": arr(info.ghost_gid, info.n_ghost), "send_ids": arr(info.send_ids, info.n_send), "send_gid": arr(info.send_gid, info.n_send),
+            "peer_rank": arr(info.peer_rank, info.npeers), "send_offset": arr(info.send_offset, info.npeers),
+            "send_count": arr(info.send_count, info.npeers), "recv_offset": arr(info.recv_offset, info.npeers),
+            "recv_count": arr(info.recv_count, info.npeers),
+        }
+    finally:
+        _capi.lib().tm_plan_local_free(C.byref(info))
+
+
+class HaloExchanger:
+    """The communication pattern of one rank, independent of where the buffers live (CUDA or CPU tensors):
+    exchange(send, recv) moves peer k's slice of `send` to that peer and fills peer k's slice of `recv`;
+    allreduce(t) sums in place.  Rows are double2, so offsets/counts are scaled by 2 doubles."""
+
+    def __init__(self, plan, group=None):
+        import torch.distributed as dist
+
+        self.dist = dist
+        self.group = group
+        self.peers = [int(p) for p in plan["peer_rank"]]
+        self.send = [(2 * int(o), 2 * int(c)) for o, c in zip(plan["send_offset"], plan["send_count"])]
+        self.recv = [(2 * int(o), 2 * int(c)) for o, c in zip(plan["recv_offset"], plan["recv_count"])]
+
+    def exchange(self, send, recv):
+        dist = self.dist
+        ops = []
+        for peer, (so, sc), (ro, rc) in zip(self.peers, self.send, self.recv):
+            if rc:
+                ops.append(dist.P2POp(dist.irecv, recv[ro:ro + rc], peer, self.group))
+            if sc:
+                ops.append(dist.P2POp(dist.isend, send[so:so + sc], peer, self.group))
+        if ops:
+            for w in dist.batch_isend_irecv(ops):
+                w.wait()   # NCCL: makes the current stream wait, the host does not block
+
+    def allreduce(self, t):
+        self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
+
+
+class HooksBase:
+    """ctypes plumbing of tm_comm_hooks on top of a torch workspace tensor."""
+
+    def __init__(self, mesh, owner, rank, world, option=None, control=None, device=None):
+        import torch
+
+        self.torch = torch
+        self.rank, self.world = rank, world
+        self._owner = (C.c_int32 * len(owner))(*owner)
+        self._exc = None
+        self._exchange_cb = _capi.EXCHANGE_FN(self._on_exchange)
+        self._allreduce_cb = _capi.ALLREDUCE_FN(self._on_allreduce)
+        hooks = _capi.tm_comm_hooks(None, rank, world, self._owner, self._exchange_cb, self._allreduce_cb, None, 0)
+        opt = (option or _solver.Option.hip()).c_struct()
+        from .smoothing import wall_control_function as _wcf
+
+        cf = (control or _wcf.Algorithm.laplace()).c_struct()
+        md = _capi.MeshDesc(mesh)
+        nbytes = C.c_uint64(0)
+        _capi.check(_capi.lib().tm_smoother_workspace_bytes(md.ref(), C.byref(opt), C.byref(cf), C.byref(hooks), C.byref(nbytes)))
+        device = device or torch.device("cuda", torch.cuda.current_device())
+        self.workspace = torch.zeros(int(nbytes.value) // 8 + 64, dtype=torch.float64, device=device)
+        self._base = self.workspace.data_ptr()
+        hooks.workspace = self._base
+        hooks.workspace_bytes = self.workspace.numel() * 8
+        self._hooks = hooks
+        self.smoother = smooth.Smoother(mesh, option, control, hooks=hooks, stream=torch.cuda.current_stream(device).cuda_stream)
+        self.plan = self._read_plan()
+        self.n_send = int(sum(self.plan["send_count"]))
+        self.n_ghost = int(sum(self.plan["recv_count"]))
+
+    def _read_plan(self):
+        n = C.c_int32(0)
+        pr = C.POINTER(C.c_int32)()
+        so, sc, ro, rc = (C.POINTER(C.c_int64)() for _ in range(4))
+        _capi.check(_capi.lib().tm_smoother_exchange_plan(self.smoother._h, C.byref(n), C.byref(pr), C.byref(so), C.byref(sc), C.byref(ro), C.byref(rc)))
+        k = n.value
+
+        def arr(ptr):
+            return np.ctypeslib.as_array(ptr, (k,)).copy() if k else np.zeros(0, dtype=np.int64)
+
+        return {"peer_rank": arr(pr), "send_offset": arr(so), "send_count": arr(sc), "recv_offset": arr(ro), "recv_count": arr(rc)}
+
+    def _view(self, ptr, ndoubles):
+        off = (int(ptr) - self._base) // 8
+        assert 0 <= off and off + ndoubles <= self.workspace.numel(), "hook pointer outside the workspace"
+        return self.workspace[off:off + ndoubles]
+
+    def _on_exchange(self, ctx, send_ptr, recv_ptr, stream):
+        try:
+            self.exchange(self._view(send_ptr, 2 * self.n_send) if self.n_send else None, self._view(recv_ptr, 2 * self.n_ghost) if self.n_ghost else None)
+            return 0
+        except BaseException as e:   # never let an exception cross the C boundary
+            self._exc = e
+            return 1
+
+    def _on_allreduce(self, ctx, buf, n, stream):
+        try:
+            self.allreduce(self._view(buf, int(n)))
+            return 0
+        except BaseException as e:
+            self._exc = e
+            return 1
+
+    def iterate(self, iterations):
+        try:
+            return self.smoother.iterate(iterations)
+        except _capi.TmError:
+            if self._exc is not None:
+                raise self._exc
+            raise
+
+    # subclasses implement the transport
+    def exchange(self, send, recv):
+        raise NotImplementedError
+
+    def allreduce(self, t):
+        raise NotImplementedError
+
+
+class TorchHooks(HooksBase):
+    """tm_comm_hooks over torch.distributed (RCCL p2p + all-reduce)."""
+
+    def __init__(self, mesh, owner, rank, world, option=None, control=None, group=None, device=None):
+        super().__init__(mesh, owner, rank, world, option, control, device)
+        self._x = HaloExchanger(self.plan, group)
+
+    def exchange(self, send, recv):
+        self._x.exchange(send, recv)
+
+    def allreduce(self, t):
+        self._x.allreduce(t)

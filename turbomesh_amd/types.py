@@ -29,6 +29,14 @@ class Mat2d:
         self.data = np.full((self.size[0], self.size[1], 2), np.nan, dtype=np.float64)
 
     @classmethod
+    def placeholder(cls, size):
+        """Sizes only (a block owned by another rank of a multi-GPU job): data is None."""
+        m = cls.__new__(cls)
+        m.size = (int(size[0]), int(size[1]))
+        m.data = None
+        return m
+
+    @classmethod
     def from_array(cls, arr):
         arr = np.ascontiguousarray(arr, dtype=np.float64)
         assert arr.ndim == 3 and arr.shape[2] == 2
