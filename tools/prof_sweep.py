@@ -1,0 +1,23 @@
+#!/usr/bin/env python3
+"""Small driver for rocprofv3 runs: N relax sweeps of the 4096^2 block through the C-ABI handle (no CPU baseline, no events)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from turbomesh_amd import _capi, configs
+from turbomesh_amd.smoothing import smooth, solver
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
+mode = sys.argv[3] if len(sys.argv) > 3 else "relax"
+ring = int(sys.argv[4]) if len(sys.argv) > 4 else -1
+if ring >= 0:
+    _capi.lib().tm_tune_ring(ring)
+mesh = configs.single_block(n, n)
+if mode == "relax":
+    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+        sm.iterate(steps)
+else:
+    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.bicgstab, max_inner=steps, rtol=1e-30)) as sm:
+        sm.iterate(1)
+print("done")

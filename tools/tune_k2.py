@@ -48,9 +48,9 @@ def timed(fn, reps=40):
 a = torch.empty(n * n * 2, dtype=torch.float64, device="cuda").normal_()
 b = torch.empty_like(a)
 L = _capi.lib()
-for rows, unroll, pipe, nt in ((32, 4, 0, 1), (64, 4, 0, 1), (64, 4, 0, 0), (64, 2, 1, 1), (32, 2, 0, 1)):
+for rows, unroll, pipe, nt in ((64, 4, 0, 1), (64, 2, 0, 1), (32, 4, 1, 1)):
     L.tm_tune_apply(rows, unroll, pipe, nt)
-    for mode, label in ((4, "diag_copy"), (5, "diag_sum9")):
+    for mode, label in ((4, "diag_copy"), (5, "diag_sum9"), (6, "diag_nostore(math+loads)"), (7, "diag_noload(math+stores)")):
         us = timed(lambda: L.tm_diag_apply(a.data_ptr(), b.data_ptr(), n, n, mode, None))
         print(os.environ.get("TM_TUNE_TAG", ""), label, "rows", rows, "U", unroll, "pipe", pipe, "nt", nt, f"{us:.1f} us (back-to-back launches incl. gaps)", f"{32.0 * n * n / us / 1e3:.0f} GB/s", flush=True)
     us = timed(lambda: L.tm_dev_relax_sweep(a.data_ptr(), b.data_ptr(), n, n, 1.0, None, 0, None, None))
@@ -59,21 +59,9 @@ del a, b
 
 mesh = configs.single_block(n, n)
 tag = os.environ.get("TM_TUNE_TAG", "default")
-for rows in (32, 64):
-    for unroll in (2, 4):
-        for pipe in (0,):
-            for nt in (0, 1):
-                _capi.lib().tm_tune_apply(rows, unroll, pipe, nt)
-                with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax)) as sm:
-                    sm.iterate(10)
-                    sm.profile(True)
-                    st = sm.iterate(steps)
-                    ms, k = sm.profile_read()
-                us = ms * 1e3 / k
-                res[f"relax_r{rows}_u{unroll}_p{pipe}_nt{nt}"] = {"us": us, "GBps": 32.0 * n * n / us / 1e3, "step_us": st["seconds"] * 1e6 / steps}
-                print(tag, "relax rows", rows, "U", unroll, "pipe", pipe, "nt", nt, f"{us:.1f} us", f"{32.0 * n * n / us / 1e3:.0f} GB/s", f"step {st['seconds'] * 1e6 / steps:.1f} us", flush=True)
+L.tm_tune_ring(8)
 # Krylov apply (48-64 B/node: frozen field + vector in, vector out) through the BiCGStab path
-for rows, unroll, pipe in ((32, 2, 0),):
+for rows, unroll, pipe in ():
     _capi.lib().tm_tune_apply(rows, unroll, pipe, 0)
     with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.bicgstab, max_inner=24, rtol=1e-30)) as sm:
         sm.profile(True)

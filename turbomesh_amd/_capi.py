@@ -150,6 +150,7 @@ def lib():
         L.tm_dev_relax_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_void_p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.c_void_p]
         L.tm_diag_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+        L.tm_tune_ring.argtypes = [C.c_int]
         L.tm_tune_apply.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib

@@ -100,6 +100,10 @@ int tm_tune_apply(int rows_per_chunk, int unroll, int pipe, int nt) {
     return TM_OK;
 }
 
+int tm_tune_ring(int depth) {
+    tune_ring(depth);
+    return TM_OK;
+}
 // diagnostic: K2 with the same tiling / data movement but reduced arithmetic (mode 4 = copy, 5 = 9-point sum)
 int tm_diag_apply(const double* d_in, double* d_out, uint64_t ni, uint64_t nj, int mode, void* stream) {
     return guarded([&]() {

@@ -15,7 +15,9 @@ enum ApplyMode : int {
     MODE_RELAX = 3,    // out = in + omega * (rhs*dinv - sum*dinv)
     // diagnostics (tools/tune_k2.py only): same tiling and data movement, reduced arithmetic
     MODE_DIAG_COPY = 4,   // out = in
-    MODE_DIAG_SUM9 = 5    // out = plain sum of the 9 neighbours (loads, halo, lane shifts; no coefficients)
+    MODE_DIAG_SUM9 = 5,   // out = plain sum of the 9 neighbours (loads, halo, lane shifts; no coefficients)
+    MODE_DIAG_NOSTORE = 6,   // full relax arithmetic, all loads, NO store (result folded into the partial sums)
+    MODE_DIAG_NOLOAD = 7     // full relax arithmetic and stores, rows are NOT re-loaded (window reused)
 };
 // ---- fused partial reductions written per workgroup (x and y components separately)
 enum DotMode : int {
@@ -39,6 +41,7 @@ struct ApplyBlock {
 };
 // number of workgroups k2 launches for a block (also the number of partial rows it writes)
 int apply_block_nwg(int ni, int nj);
+void tune_ring(int depth);   // LDS-DMA ring depth of the field-mode relax kernel (0 = register path)
 void tune_apply(int rows_per_chunk, int unroll, int pipe, int nt);   // <=0 (pipe, nt: <0) keeps the current value
 hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_t stream);
 

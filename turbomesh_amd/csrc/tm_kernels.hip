@@ -25,6 +25,7 @@
 // Workgroup ids are remapped so that every XCD (own L2) walks a contiguous range of
 // (row-chunk, strip) tiles: the halo lines shared by neighbouring tiles hit in that L2.
 #include "tm_kernels.h"
+#include <type_traits>
 
 namespace tmh {
 
@@ -193,9 +194,9 @@ __device__ __forceinline__ double2 winslow_row(double2 m_l, double2 m_c, double2
 //     BiCGStab.zig:424-435 mat-vec), matrix-free, factored row evaluation (winslow_row)
 // ------------------------------------------------------------------------------------------
 static int g_rows_per_chunk = 64;   // tunable (tm_tune_apply)
-static int g_unroll = 2;
-static int g_pipe = 1;
-static int g_nt = 0;
+static int g_unroll = 4;
+static int g_pipe = 0;
+static int g_nt = 1;
 
 typedef double d2v __attribute__((ext_vector_type(2)));
 
@@ -228,7 +229,7 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
         auto load_row = [&](const double2* __restrict__ v, int row, double2& c, double2& h) {
             const double2* rp = v + static_cast<size_t>(row) * nj;
             c = rp[jc];
-            h = c;
+            h = make_double2(0.0, 0.0);   // NOT `h = c`: that copy would force a vmcnt(0) wait right behind every row load
             if (edge_lane) h = rp[hcol];
         };
         // 3-row window of the vector: m = row i-1, c = row i, p = row i+1; l/r = columns j-1/j+1
@@ -254,7 +255,11 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int prow = min(ib + u + 1, ni - 1);
-                load_row(a.in, prow, g.pc[u], g.ph[u]);
+                if (MODE == MODE_DIAG_NOLOAD) {
+                    g.pc[u] = wc_c;
+                    g.ph[u] = wc_h;
+                } else
+                    load_row(a.in, prow, g.pc[u], g.ph[u]);
                 if (!FIELD) load_row(a.xk, prow, g.xpc[u], g.xph[u]);
                 const size_t cur = static_cast<size_t>(min(ib + u, ni - 2)) * nj + jc;
                 if (HAS_PQ) g.pqv[u] = a.pq[cur];
@@ -275,12 +280,17 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
                 } else if (MODE == MODE_DIAG_SUM9) {
                     o.x = wm_l.x + wm_c.x + wm_r.x + wc_l.x + wc_c.x + wc_r.x + wp_l.x + wp_c.x + wp_r.x;
                     o.y = wm_l.y + wm_c.y + wm_r.y + wc_l.y + wc_c.y + wc_r.y + wp_l.y + wp_c.y + wp_r.y;
+                } else if (MODE == MODE_DIAG_NOSTORE || MODE == MODE_DIAG_NOLOAD) {
+                    o = winslow_row<MODE_RELAX, HAS_PQ>(wm_l, wm_c, wm_r, wc_l, wc_c, wc_r, wp_l, wp_c, wp_r, wm_c, wp_c, wc_l, wc_r, P, Q, a.omega);
                 } else if (FIELD) {
                     o = winslow_row<MODE, HAS_PQ>(wm_l, wm_c, wm_r, wc_l, wc_c, wc_r, wp_l, wp_c, wp_r, wm_c, wp_c, wc_l, wc_r, P, Q, a.omega);
                 } else {
                     o = winslow_row<MODE, HAS_PQ>(wm_l, wm_c, wm_r, wc_l, wc_c, wc_r, wp_l, wp_c, wp_r, xm_c, g.xpc[u], xc_l, xc_r, P, Q, a.omega);
                 }
-                if (row < i1 && valid_col) {
+                if (MODE == MODE_DIAG_NOSTORE) {
+                    acc[0] += o.x;
+                    acc[1] += o.y;
+                } else if (row < i1 && valid_col) {
                     double2* dst = a.out + static_cast<size_t>(row) * nj + j;
                     if (NT) {
                         d2v ov;
@@ -327,7 +337,133 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
             }
         }
     }
+    if (MODE == MODE_DIAG_NOSTORE && acc[0] + acc[1] == 123.456) a.out[0] = make_double2(acc[0], acc[1]);   // keep the arithmetic live
     if (DOT != DOT_NONE) block_partials<256>(acc, a.partials + static_cast<size_t>(bid) * MAX_PARTIALS);
+}
+
+// ------------------------------------------------------------------------------------------
+// K2, LDS-DMA ring variant (field mode, Laplace): the same marching tile, but every wave streams
+// its rows HBM -> LDS with `global_load_lds_dwordx4` (no VGPR destination) into a private ring of
+// R row slots, so R-1 rows (about R KiB per wave, >100 KB per CU) are in flight while the wave
+// computes -- the register path can only keep what its VGPR budget holds.  A slot holds the 66
+// columns j0-1 .. j0+64, so the j-1 / j+1 neighbours are plain ds_read_b128 at +-16 B: no lane
+// shifts, no halo registers.  hipcc does not count LDS-DMA, so completion is tracked by hand:
+// VMEM operations retire in issue order and the only other VMEM operation in the loop is the one
+// store per row, hence "row q has landed" == `s_waitcnt vmcnt(<ops issued after row q's DMAs>)`.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
+    unsigned keep;
+    // lgkmcnt(0): the slot's previous occupant has been read out before the DMA may overwrite it
+    asm volatile(
+        "s_waitcnt lgkmcnt(0)\n\t"
+        "s_mov_b32 %0, m0\n\t"
+        "s_mov_b32 m0, %2\n\t"
+        "s_nop 0\n\t"
+        "global_load_lds_dwordx4 %1, off\n\t"
+        "s_mov_b32 m0, %0"
+        : "=&s"(keep)
+        : "v"(gsrc), "s"(lds_dst)
+        : "memory");
+}
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+static int g_ring = 0;   // ring depth R (0 = use the register path, the default: same speed, simpler)
+
+template <int MODE, int DOT, int R, bool NT>
+__global__ __launch_bounds__(256) void k_apply_ring(ApplyBlock a, int RI, int nSG, int nRC) {
+    constexpr int SLOT = 66 * 16;   // bytes per row slot
+    __shared__ __attribute__((aligned(16))) char lds[4 * R * SLOT];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int total = nSG * nRC;
+    const int bid = blockIdx.x;
+    const int q8 = total >> 3, rem = total & 7, xcd = bid & 7, k8 = bid >> 3;
+    const int logical = (xcd < rem) ? xcd * (q8 + 1) + k8 : rem * (q8 + 1) + (xcd - rem) * q8 + k8;
+    const int rc = logical / nSG;
+    const int sg = logical - rc * nSG;
+
+    const int ni = a.ni, nj = a.nj;
+    const int j0 = (sg * 4 + wave) * 64;
+    const int j = j0 + lane;
+    const bool valid_col = (j >= 1) && (j <= nj - 2);
+    const int i0 = 1 + rc * RI;
+    const int i1 = min(i0 + RI, ni - 1);   // output rows [i0, i1)
+
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+
+    // a wave takes part only if it owns at least one output column (keeps the VMEM op count per row exact)
+    if (max(j0, 1) <= min(j0 + 63, nj - 2) && i0 < i1) {   // wave-uniform
+        const unsigned wbase = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds)) + static_cast<unsigned>(wave * R * SLOT);
+        const int c_main = min(max(j0 - 1 + lane, 0), nj - 1);    // slot element e <-> column j0-1+e
+        const int c_tail = min(j0 + 63 + lane, nj - 1);            // lanes 0,1: elements 64,65
+        auto dma_row = [&](int qrow, int slot) {
+            const double2* rp = a.in + static_cast<size_t>(min(qrow, ni - 1)) * nj;
+            const unsigned dst = wbase + static_cast<unsigned>(slot * SLOT);
+            glds16(rp + c_main, dst);
+            if (lane < 2) glds16(rp + c_tail, dst + 1024u);
+        };
+        int q = i0 - 1;
+#pragma unroll
+        for (int k = 0; k < R; ++k) dma_row(q + k, k);   // prologue: R rows in flight
+
+        double2 m_l, m_c, m_r, c_l, c_c, c_r;
+        m_l = m_c = m_r = c_l = c_c = c_r = make_double2(0.0, 0.0);
+        int slot = 0;
+        auto step = [&](auto nwait) {
+            constexpr int N = decltype(nwait)::value;
+            wait_vmcnt<N>();   // row q has landed in its slot
+            const double2* srow = reinterpret_cast<const double2*>(lds + wave * R * SLOT + slot * SLOT);
+            const double2 p_l = srow[lane], p_c = srow[lane + 1], p_r = srow[lane + 2];
+            dma_row(q + R, slot);   // refill the slot (glds16 waits lgkmcnt(0) first)
+            if (q >= i0 + 1) {
+                const int row = q - 1;
+                const double2 o = winslow_row<MODE, false>(m_l, m_c, m_r, c_l, c_c, c_r, p_l, p_c, p_r, m_c, p_c, c_l, c_r, 0.0, 0.0, a.omega);
+                if (valid_col) {
+                    double2* dst = a.out + static_cast<size_t>(row) * nj + j;
+                    if (NT) {
+                        d2v ov;
+                        ov.x = o.x;
+                        ov.y = o.y;
+                        __builtin_nontemporal_store(ov, reinterpret_cast<d2v*>(dst));
+                    } else {
+                        *dst = o;
+                    }
+                    accumulate<DOT>(acc, c_c, o, o);
+                }
+            }
+            m_l = c_l; m_c = c_c; m_r = c_r;
+            c_l = p_l; c_c = p_c; c_r = p_r;
+            slot = (slot + 1 == R) ? 0 : slot + 1;
+            q += 1;
+        };
+        // ops issued after row q's two DMAs: the DMAs of rows q+1..q+R-1, plus one store per step since then.
+        // Warm-up (fewer stores issued so far): wait with the store-free count (conservative, always safe).
+        constexpr int N_WARM = 2 * (R - 1);
+        constexpr int N_STEADY = 2 * (R - 1) + R;
+        const int q_steady = i0 + R + 1;
+        while (q <= i1 && q < q_steady) step(std::integral_constant<int, N_WARM>{});
+        while (q <= i1) step(std::integral_constant<int, N_STEADY>{});
+        wait_vmcnt<0>();   // no LDS-DMA may outlive the wave
+    }
+    if (DOT != DOT_NONE) block_partials<256>(acc, a.partials + static_cast<size_t>(bid) * MAX_PARTIALS);
+}
+
+template <int MODE, int DOT>
+static hipError_t launch_apply_ring(const ApplyBlock& a, int RI, int nSG, int nRC, hipStream_t st) {
+    const dim3 grid(nSG * nRC), block(256);
+#define TM_RING(R_) do { if (g_nt) hipLaunchKernelGGL((k_apply_ring<MODE, DOT, R_, true>), grid, block, 0, st, a, RI, nSG, nRC); \
+                         else hipLaunchKernelGGL((k_apply_ring<MODE, DOT, R_, false>), grid, block, 0, st, a, RI, nSG, nRC); } while (0)
+    switch (g_ring) {
+        case 4: TM_RING(4); break;
+        case 6: TM_RING(6); break;
+        case 12: TM_RING(12); break;
+        default: TM_RING(8); break;
+    }
+#undef TM_RING
+    return hipGetLastError();
 }
 
 static inline int rows_per_chunk(int ni) {
@@ -386,13 +522,20 @@ hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_
     if (mode == MODE_SCALED && dot == DOT_IN) return launch_apply_md<MODE_SCALED, DOT_IN>(a, RI, nSG, nRC, st);
     if (mode == MODE_RESID && dot == DOT_OUT2) return launch_apply_md<MODE_RESID, DOT_OUT2>(a, RI, nSG, nRC, st);
     if (mode == MODE_RESID && dot == DOT_NONE) return launch_apply_md<MODE_RESID, DOT_NONE>(a, RI, nSG, nRC, st);
+    if (mode == MODE_RELAX && g_ring > 0 && a.in == a.xk && a.pq == nullptr) {   // field mode, Laplace: LDS-DMA ring
+        if (dot == DOT_DELTA) return launch_apply_ring<MODE_RELAX, DOT_DELTA>(a, RI, nSG, nRC, st);
+        if (dot == DOT_NONE) return launch_apply_ring<MODE_RELAX, DOT_NONE>(a, RI, nSG, nRC, st);
+    }
     if (mode == MODE_RELAX && dot == DOT_DELTA) return launch_apply_md<MODE_RELAX, DOT_DELTA>(a, RI, nSG, nRC, st);
     if (mode == MODE_RELAX && dot == DOT_NONE) return launch_apply_md<MODE_RELAX, DOT_NONE>(a, RI, nSG, nRC, st);
     if (mode == MODE_DIAG_COPY) return launch_apply_md<MODE_DIAG_COPY, DOT_NONE>(a, RI, nSG, nRC, st);
     if (mode == MODE_DIAG_SUM9) return launch_apply_md<MODE_DIAG_SUM9, DOT_NONE>(a, RI, nSG, nRC, st);
+    if (mode == MODE_DIAG_NOSTORE) return launch_apply_md<MODE_DIAG_NOSTORE, DOT_NONE>(a, RI, nSG, nRC, st);
+    if (mode == MODE_DIAG_NOLOAD) return launch_apply_md<MODE_DIAG_NOLOAD, DOT_NONE>(a, RI, nSG, nRC, st);
     return hipErrorInvalidValue;
 }
 
+void tune_ring(int depth) { g_ring = depth; }
 void tune_apply(int rows, int unroll, int pipe, int nt) {
     if (rows > 0) g_rows_per_chunk = rows;
     if (unroll == 1 || unroll == 2 || unroll == 4) g_unroll = unroll;
