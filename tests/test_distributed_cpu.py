@@ -1,0 +1,124 @@
+"""CPU, world_size 2 and 3 over gloo: the N>1 path's host logic -- rank-local plans (tm_plan_local, no GPU) and the
+torch.distributed halo exchange / all-reduce of turbomesh_amd.distributed.HaloExchanger (the same code the RCCL job runs,
+on CPU tensors).  Checks:
+  - every rank's ghost rows arrive with exactly the owner's values (pack order, peer offsets, p2p pairing);
+  - the ghost set is sufficient: every column of every owned perimeter row is owned or ghost, so the row-wise
+    mat-vec assembled from rank-local data equals the global oracle mat-vec (reference smooth.zig rows);
+  - the partition is a partition (owned rows of all ranks = all rows, no overlap); all-reduce sums."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from oracle import oracle
+from tests.conftest import OracleMesh, oracle_tfi
+from turbomesh_amd import configs, distributed as tmd
+from turbomesh_amd.smoothing import smooth
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _mesh(kind):
+    if kind == "strip4":
+        return configs.strip(4, 9, 12, tfi=oracle_tfi, reverse_odd=True)
+    if kind == "two_by_two":
+        return configs.two_by_two(8, 9, tfi=oracle_tfi)
+    raise ValueError(kind)
+
+
+def _worker(rank, world, port, kind, owner, q):
+    try:
+        dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+        mesh = _mesh(kind)
+        om = OracleMesh(mesh)
+        s = oracle.System(om)
+        s.fill(0)
+        dof = s.dof
+        rng = np.random.default_rng(123)           # the same global vector on every rank
+        v = rng.standard_normal((dof, 2))
+        plan = tmd.local_plan(mesh, owner, rank, world)
+        n_owned, n_ghost = plan["n_owned"], plan["n_ghost"]
+        starts = np.cumsum([0] + [b.points.data.shape[0] * b.points.data.shape[1] for b in mesh.blocks])
+        owned_gid = np.concatenate([np.arange(starts[b], starts[b + 1]) for b in plan["owned_blocks"]]) if len(plan["owned_blocks"]) else np.zeros(0, int)
+        assert len(owned_gid) == n_owned
+        local = np.full((n_owned + n_ghost, 2), np.nan)
+        local[:n_owned] = v[owned_gid]
+        # pack -> exchange -> ghosts
+        send = torch.from_numpy(local[plan["send_ids"]].reshape(-1).copy()) if plan["n_send"] else torch.zeros(0, dtype=torch.float64)
+        assert np.array_equal(owned_gid[plan["send_ids"]], plan["send_gid"])
+        recv = torch.full((2 * n_ghost,), float("nan"), dtype=torch.float64)
+        x = tmd.HaloExchanger(plan)
+        x.exchange(send, recv)
+        local[n_owned:] = recv.numpy().reshape(-1, 2)
+        assert np.array_equal(local[n_owned:], v[plan["ghost_gid"]]), "ghost rows differ from the owner's values"
+        # row-wise mat-vec of the owned PERIMETER rows from rank-local data only
+        g2l = {int(g): k for k, g in enumerate(owned_gid)}
+        g2l.update({int(g): n_owned + k for k, g in enumerate(plan["ghost_gid"])})
+        rows = smooth.plan_rows(mesh)
+        A = s.csr()
+        ref = np.stack([A @ v[:, 0], A @ v[:, 1]], 1)
+        mine = [k for k, g in enumerate(rows["row"]) if int(g) in g2l and g2l[int(g)] < n_owned]
+        for k in mine:
+            g = int(rows["row"][k])
+            cols = rows["cols"][k, :rows["ncols"][k]]
+            assert all(int(c) in g2l for c in cols), f"rank {rank}: row {g} reads a row that is neither owned nor ghost"
+            r = A.getrow(g)
+            acc = np.zeros(2)
+            for c, a in zip(r.indices, r.data):
+                acc = acc + a * local[g2l[int(c)]]
+            assert np.allclose(acc, ref[g], rtol=1e-13, atol=1e-13)
+        # partition check + all-reduce
+        t = torch.tensor([float(n_owned), float(len(mine)), 1.0, float(rank)], dtype=torch.float64)
+        x.allreduce(t)
+        assert int(t[0]) == dof and int(t[1]) == len(rows["row"]) and int(t[2]) == world and int(t[3]) == sum(range(world))
+        dist.barrier()
+        dist.destroy_process_group()
+        q.put((rank, "ok"))
+    except Exception as e:  # pragma: no cover
+        import traceback
+
+        q.put((rank, "".join(traceback.format_exception(type(e), e, e.__traceback__))))
+
+
+@pytest.mark.parametrize("kind,world,owner", [
+    ("strip4", 2, [0, 0, 1, 1]),
+    ("strip4", 2, [0, 1, 0, 1]),          # interleaved ownership: every interface crosses ranks
+    ("strip4", 3, [0, 1, 2, 2]),
+    ("two_by_two", 2, [0, 1, 1, 0]),      # junction point shared by both ranks
+])
+def test_halo_exchange_and_plan_over_gloo(kind, world, owner):
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, kind, owner, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, res in sorted(results):
+        assert res == "ok", f"rank {rank}:\n{res}"
+
+
+def test_local_plan_single_rank_has_no_ghosts():
+    mesh = _mesh("strip4")
+    plan = tmd.local_plan(mesh, [0, 0, 0, 0], 0, 1)
+    assert plan["n_ghost"] == 0 and plan["n_send"] == 0 and len(plan["peer_rank"]) == 0
+    assert plan["n_owned"] == 4 * 9 * 12
+
+
+def test_strip_for_rank_matches_full_strip():
+    full = configs.strip(4, 9, 12, tfi=oracle_tfi)
+    part = configs.strip(4, 9, 12, tfi=oracle_tfi, only_blocks={2})
+    assert part.blocks[0].points.data is None and part.blocks[2].points.data is not None
+    assert np.array_equal(part.blocks[2].points.data, full.blocks[2].points.data)   # interface curves are bitwise reproducible per rank

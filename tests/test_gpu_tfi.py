@@ -37,7 +37,7 @@ def test_tfi_bit_exact_uniform(ni, nj):
 @pytest.mark.parametrize("ni,nj", [(33, 41), (129, 130)])
 def test_tfi_bit_exact_mixed_clusterings(ni, nj):
     # opposite edges clustered differently: exercises the boundary-blended u,v (tfi.zig:185-186)
-    e = _curved_edges(ni, nj, clustering.Uniform(), clustering.Roberts(0.5, 1.05), clustering.SingleHyperbolicClustering(0.01), clustering.Roberts(0.0, 1.2))
+    e = _curved_edges(ni, nj, clustering.Uniform(), clustering.Roberts(0.5, 1.05), clustering.SingleHyperbolicClustering(0.002), clustering.Roberts(0.0, 1.2))
     got = Block2d.init(*e).points.data
     ref = oracle.tfi_block(e[0].points, e[1].points, e[2].points, e[3].points, e[0].clustering, e[1].clustering, e[2].clustering, e[3].clustering)
     assert got.tobytes() == ref.tobytes()
