@@ -113,4 +113,6 @@ def test_multi_rank_equals_single_rank(name, builder, owner):
     smooth.mesh(ref, 3, opt)
     got = _run_ranks(builder, owner, opt, 3)
     rms = float(np.sqrt(np.mean((mesh_flat(got) - mesh_flat(ref)) ** 2)))
-    assert rms <= 1e-10, (name, rms)
+    # both runs solve the same frozen systems to rtol 1e-13 with different reduction orders; each is within 1e-10 RMS of the
+    # exact iterate (tests/test_gpu_smooth.py), so they may differ from each other by up to twice that
+    assert rms <= 2e-10, (name, rms)
