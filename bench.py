@@ -45,7 +45,7 @@ def cpu_baseline(n, budget_s=15.0):
     mesh = configs.single_block(e_n, e_n, tfi=tfi_cpu)
     xy = mesh.blocks[0].points.data
     t1 = oracle.time_relax_sweeps(xy, 1)          # warm-up + calibration
-    sweeps = max(1, min(64, int(budget_s / max(t1, 1e-3))))
+    sweeps = max(1, min(512, int(budget_s / max(t1, 1e-3))))
     t = oracle.time_relax_sweeps(xy, sweeps)
     # reference-style inner iteration for context: assembled CSR + BiCGStab(diagonal), 2 mat-vecs per iteration
     sub = configs.single_block(1024, 1024, tfi=tfi_cpu).blocks[0].points.data
@@ -65,6 +65,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--n", type=int, default=4096, help="block edge (nodes); 4096 is the BASELINE config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (RCCL hooks) even with one rank")
     ap.add_argument("--rows", type=int, default=0, help="K2 rows per chunk (tuning)")
     ap.add_argument("--unroll", type=int, default=0, help="K2 row unroll (tuning)")
     ap.add_argument("--pipe", type=int, default=-1, help="K2 software pipelining 0/1 (tuning)")
@@ -92,11 +93,13 @@ def main():
     n = args.n
     dist = None
     hooks_obj = None
-    if world > 1:
+    if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
 
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if "MASTER_ADDR" not in os.environ:   # --force-dist without a launcher
+            os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         from turbomesh_amd import distributed as tmd
 
         mesh = tmd.strip_for_rank(world, rank, n, n)                        # only the owned block carries coordinates

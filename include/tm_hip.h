@@ -169,6 +169,10 @@ typedef struct tm_comm_hooks {
     const int32_t* owner;   /* [nblocks] */
     int (*exchange)(void* ctx, const double* send_buf, double* recv_buf, void* stream);
     int (*allreduce_sum)(void* ctx, double* buf, int32_t n, void* stream);
+    /* Optional split form: when exchange_wait != NULL, exchange() only STARTS the transfer (it may return before the
+     * ghost rows have arrived) and exchange_wait() makes `stream` wait for it.  The library then runs the interior-row
+     * kernel K2 -- which never reads ghost rows -- between the two, hiding the transfer behind it. */
+    int (*exchange_wait)(void* ctx, void* stream);
     /* Optional caller-provided device memory (e.g. a torch tensor, so the hooks can hand views of it to
      * torch.distributed): when workspace != NULL every device buffer of the handle is carved from it.
      * Size it with tm_smoother_workspace_bytes. */

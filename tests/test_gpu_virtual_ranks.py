@@ -58,7 +58,26 @@ class ThreadHooks(HooksBase):
         t.copy_(total)
 
 
-def _run_ranks(builder, owner, option, iterations, rounds=1):
+class SplitThreadHooks(ThreadHooks):
+    """Split form: exchange() posts the copies, exchange_wait() closes the phase (the library runs K2 in between)."""
+
+    def exchange(self, send, recv):
+        sh = self.shared
+        sh.send[self.rank] = send
+        sh.barrier.wait()
+        for k, peer in enumerate(self.plan["peer_rank"]):
+            ro, rc = 2 * int(self.plan["recv_offset"][k]), 2 * int(self.plan["recv_count"][k])
+            pp = sh.plan[int(peer)]
+            idx = list(pp["peer_rank"]).index(self.rank)
+            so, sc = 2 * int(pp["send_offset"][idx]), 2 * int(pp["send_count"][idx])
+            if rc:
+                recv[ro:ro + rc].copy_(sh.send[int(peer)][so:so + sc])
+
+    def exchange_wait(self):
+        self.shared.barrier.wait()
+
+
+def _run_ranks(builder, owner, option, iterations, rounds=1, hooks_cls=None):
     world = max(owner) + 1
     shared = _Shared(world)
     meshes = [builder() for _ in range(world)]
@@ -69,7 +88,7 @@ def _run_ranks(builder, owner, option, iterations, rounds=1):
     def work(r):
         try:
             with create_lock:   # creation uploads with blocking copies; keep it simple
-                hooks[r] = ThreadHooks(shared, meshes[r], owner, r, world, option)
+                hooks[r] = (hooks_cls or ThreadHooks)(shared, meshes[r], owner, r, world, option)
             shared.barrier.wait()
             for _ in range(rounds):
                 hooks[r].iterate(iterations)
@@ -106,6 +125,8 @@ def test_multi_rank_equals_single_rank(name, builder, owner):
     ref = builder()
     smooth.mesh(ref, 25, opt)
     got = _run_ranks(builder, owner, opt, 25)
+    assert np.array_equal(mesh_flat(got), mesh_flat(ref)), name
+    got = _run_ranks(builder, owner, opt, 25, hooks_cls=SplitThreadHooks)   # overlapped exchange: same bits
     assert np.array_equal(mesh_flat(got), mesh_flat(ref)), name
     # Picard + BiCGStab: reduction order differs across ranks -> tolerance
     opt = solver.Option.hip(rtol=1e-13, max_inner=5000)

@@ -74,11 +74,13 @@ class tm_stats(C.Structure):
 
 EXCHANGE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p)
+EXCHANGE_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
 
 class tm_comm_hooks(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int32), ("nranks", C.c_int32), ("owner", C.POINTER(C.c_int32)),
-                ("exchange", EXCHANGE_FN), ("allreduce_sum", ALLREDUCE_FN), ("workspace", C.c_void_p), ("workspace_bytes", C.c_uint64)]
+                ("exchange", EXCHANGE_FN), ("allreduce_sum", ALLREDUCE_FN), ("exchange_wait", EXCHANGE_WAIT_FN), ("workspace", C.c_void_p),
+                ("workspace_bytes", C.c_uint64)]
 
 
 class tm_plan_rows(C.Structure):

@@ -131,12 +131,13 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     dof_global = topo.dof;
     try {
         all_rows = build_rows(topo);
-        has_hooks = h != nullptr && h->nranks > 1;
+        has_hooks = h != nullptr && h->nranks >= 1 && h->exchange != nullptr && h->allreduce_sum != nullptr;
         if (h) hooks = *h;
         owner.assign(topo.nblocks(), 0);
         int rank = 0, nranks = 1;
         if (has_hooks) {
-            if (!h->owner || !h->exchange || !h->allreduce_sum) throw TmError(TM_E_ARG, "multi-rank hooks need owner, exchange and allreduce_sum");
+            if (!h->owner) throw TmError(TM_E_ARG, "hooks need the block -> rank owner table");
+            if (h->rank < 0 || h->rank >= h->nranks) throw TmError(TM_E_ARG, "hooks: rank outside [0, nranks)");
             rank = h->rank;
             nranks = h->nranks;
             owner.assign(h->owner, h->owner + topo.nblocks());
@@ -303,6 +304,14 @@ void Smoother::exchange(double2* vec) {
     HIPCHK(launch_gather_rows(vec, d_send_ids, n_send, d_send_buf, stream));
     const int rc = hooks.exchange(hooks.ctx, reinterpret_cast<const double*>(d_send_buf), reinterpret_cast<double*>(vec + n_owned), stream);
     if (rc != 0) throw TmError(TM_E_COMM, "halo exchange hook failed with code " + std::to_string(rc));
+    exchange_pending = hooks.exchange_wait != nullptr;
+}
+
+void Smoother::exchange_finish() {
+    if (!exchange_pending) return;
+    exchange_pending = false;
+    const int rc = hooks.exchange_wait(hooks.ctx, stream);
+    if (rc != 0) throw TmError(TM_E_COMM, "halo exchange wait hook failed with code " + std::to_string(rc));
 }
 
 void Smoother::reduce(int nwg) {
@@ -344,6 +353,7 @@ void Smoother::apply(const double2* in, double2* out, int mode, int dot, const d
             HIPCHK(launch_apply_block(a, mode, dot, stream));
         }
     }
+    exchange_finish();   // K2 above read owned rows only; the perimeter rows below read the ghost rows
     HIPCHK(launch_edge_rows(edge, in, xk, PQ, aux, out, omega, mode, dot, partials + static_cast<size_t>(poff_edge) * MAX_PARTIALS, stream));
     if (dot != DOT_NONE && dot != DOT_DELTA) reduce(nwg_apply);   // relax sweeps leave the per-workgroup partials; summed when read
 }
@@ -374,6 +384,7 @@ void Smoother::white_launch(int update) {
 int Smoother::picard_bicgstab(tm_stats& st) {
     if (white && outer_done > 0) white_launch(1);   // system.fill(n): control_function.update for n > 0 (smooth.zig:1107-1110)
     exchange(X);
+    exchange_finish();
     // warm start: the solution vector starts from the current coordinates (BiCGStab.zig:136-153; later
     // outer iterations continue from the copied-back solution, which is the same field)
     HIPCHK(hipMemcpyAsync(U, X, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));

@@ -87,7 +87,9 @@ struct Smoother {
     void control_function_host(double* pq);
 
     // building blocks
-    void exchange(double2* vec);
+    void exchange(double2* vec);        // start (and, without a split hook, finish) the halo exchange of `vec`
+    void exchange_finish();             // split hooks: make the stream wait for the transfer started by exchange()
+    bool exchange_pending = false;
     void apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega);
     void reduce(int nwg);   // partials -> red (+ all-reduce)
     void white_launch(int update);

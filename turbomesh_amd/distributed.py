@@ -52,8 +52,10 @@ def local_plan(mesh, owner, rank, world):
 
 class HaloExchanger:
     """The communication pattern of one rank, independent of where the buffers live (CUDA or CPU tensors):
-    exchange(send, recv) moves peer k's slice of `send` to that peer and fills peer k's slice of `recv`;
-    allreduce(t) sums in place.  Rows are double2, so offsets/counts are scaled by 2 doubles."""
+    start(send, recv) posts one grouped isend/irecv pair per neighbouring rank (peer k's slice of `send` goes to that peer,
+    its rows land in peer k's slice of `recv`), wait() completes them; allreduce(t) sums in place.
+    Rows are double2, so offsets/counts are scaled by 2 doubles.  The op lists are cached per (send, recv) buffer pair:
+    the library alternates between a few fixed buffers, and building P2POps costs as much host time as a small kernel."""
 
     def __init__(self, plan, group=None):
         import torch.distributed as dist
@@ -63,8 +65,10 @@ class HaloExchanger:
         self.peers = [int(p) for p in plan["peer_rank"]]
         self.send = [(2 * int(o), 2 * int(c)) for o, c in zip(plan["send_offset"], plan["send_count"])]
         self.recv = [(2 * int(o), 2 * int(c)) for o, c in zip(plan["recv_offset"], plan["recv_count"])]
+        self._ops = {}
+        self._works = []
 
-    def exchange(self, send, recv):
+    def _build(self, send, recv):
         dist = self.dist
         ops = []
         for peer, (so, sc), (ro, rc) in zip(self.peers, self.send, self.recv):
@@ -72,9 +76,23 @@ class HaloExchanger:
                 ops.append(dist.P2POp(dist.irecv, recv[ro:ro + rc], peer, self.group))
             if sc:
                 ops.append(dist.P2POp(dist.isend, send[so:so + sc], peer, self.group))
-        if ops:
-            for w in dist.batch_isend_irecv(ops):
-                w.wait()   # NCCL: makes the current stream wait, the host does not block
+        return ops
+
+    def start(self, send, recv):
+        key = (send.data_ptr() if send is not None else 0, recv.data_ptr() if recv is not None else 0)
+        ops = self._ops.get(key)
+        if ops is None:
+            ops = self._ops[key] = self._build(send, recv)
+        self._works = self.dist.batch_isend_irecv(ops) if ops else []
+
+    def wait(self):
+        for w in self._works:
+            w.wait()   # NCCL: makes the current stream wait, the host does not block
+        self._works = []
+
+    def exchange(self, send, recv):
+        self.start(send, recv)
+        self.wait()
 
     def allreduce(self, t):
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
@@ -92,7 +110,10 @@ class HooksBase:
         self._exc = None
         self._exchange_cb = _capi.EXCHANGE_FN(self._on_exchange)
         self._allreduce_cb = _capi.ALLREDUCE_FN(self._on_allreduce)
-        hooks = _capi.tm_comm_hooks(None, rank, world, self._owner, self._exchange_cb, self._allreduce_cb, None, 0)
+        split = type(self).exchange_wait is not HooksBase.exchange_wait   # subclass implements the split form
+        self._wait_cb = _capi.EXCHANGE_WAIT_FN(self._on_exchange_wait) if split else _capi.EXCHANGE_WAIT_FN()
+        self._views = {}
+        hooks = _capi.tm_comm_hooks(None, rank, world, self._owner, self._exchange_cb, self._allreduce_cb, self._wait_cb, None, 0)
         opt = (option or _solver.Option.hip()).c_struct()
         from .smoothing import wall_control_function as _wcf
 
@@ -124,15 +145,27 @@ class HooksBase:
         return {"peer_rank": arr(pr), "send_offset": arr(so), "send_count": arr(sc), "recv_offset": arr(ro), "recv_count": arr(rc)}
 
     def _view(self, ptr, ndoubles):
-        off = (int(ptr) - self._base) // 8
-        assert 0 <= off and off + ndoubles <= self.workspace.numel(), "hook pointer outside the workspace"
-        return self.workspace[off:off + ndoubles]
+        key = (int(ptr), ndoubles)
+        v = self._views.get(key)
+        if v is None:
+            off = (int(ptr) - self._base) // 8
+            assert 0 <= off and off + ndoubles <= self.workspace.numel(), "hook pointer outside the workspace"
+            v = self._views[key] = self.workspace[off:off + ndoubles]
+        return v
 
     def _on_exchange(self, ctx, send_ptr, recv_ptr, stream):
         try:
             self.exchange(self._view(send_ptr, 2 * self.n_send) if self.n_send else None, self._view(recv_ptr, 2 * self.n_ghost) if self.n_ghost else None)
             return 0
         except BaseException as e:   # never let an exception cross the C boundary
+            self._exc = e
+            return 1
+
+    def _on_exchange_wait(self, ctx, stream):
+        try:
+            self.exchange_wait()
+            return 0
+        except BaseException as e:
             self._exc = e
             return 1
 
@@ -152,8 +185,11 @@ class HooksBase:
                 raise self._exc
             raise
 
-    # subclasses implement the transport
+    # subclasses implement the transport; overriding exchange_wait selects the split (overlapped) form
     def exchange(self, send, recv):
+        raise NotImplementedError
+
+    def exchange_wait(self):
         raise NotImplementedError
 
     def allreduce(self, t):
@@ -167,8 +203,11 @@ class TorchHooks(HooksBase):
         super().__init__(mesh, owner, rank, world, option, control, device)
         self._x = HaloExchanger(self.plan, group)
 
-    def exchange(self, send, recv):
-        self._x.exchange(send, recv)
+    def exchange(self, send, recv):      # starts the transfer; K2 runs while it is in flight
+        self._x.start(send, recv)
+
+    def exchange_wait(self):
+        self._x.wait()
 
     def allreduce(self, t):
         self._x.allreduce(t)
