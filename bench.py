@@ -72,6 +72,12 @@ def main():
     ap.add_argument("--nt", type=int, default=-1, help="K2 non-temporal stores 0/1 (tuning)")
     args = ap.parse_args()
 
+    # Libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on stdout, so everything
+    # else goes to stderr and the JSON is written to the saved descriptor at the end.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
+
     import numpy as np
     import torch
 
@@ -163,7 +169,8 @@ def main():
             out["cpu_baseline"] = cpu_baseline(n)
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
-        print(json.dumps(out))
+        sys.stdout.flush()
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -1,0 +1,131 @@
+// harness.cpp -- plays the role of the Zig caller (reference src/gui/main.zig:30-56, src/wasm/lib.zig:35-55):
+// build edges -> Block2d.init (TFI on the MI355X) -> Mesh with connections -> smooth.mesh -> log like the reference.
+//
+//   tm_harness strip <nblocks> <ni> <nj> <iterations> [relax|bicgstab] [dump.bin]
+//   tm_harness single <ni> <nj> <iterations> [relax|bicgstab] [dump.bin]
+//
+// The synthetic edges are those of SURVEY.md 8d (config 2 / config 4), identical to turbomesh_amd/configs.py.
+// dump.bin (optional): all block coordinates as raw f64 after smoothing, for the parity test.
+#include "turbomesh.hpp"
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+
+using namespace core;
+using discrete::Block2d;
+using discrete::Edge;
+using types::Vec2d;
+
+static Edge uniformEdge(std::vector<Vec2d> pts) {
+    Edge e;
+    e.clustering = clustering::create(clustering::Uniform{}, pts.size());
+    e.points = std::move(pts);
+    return e;
+}
+static void snap(Block2d& b, const Edge& i_min, const Edge& i_max, const Edge& j_min, const Edge& j_max) {
+    const std::size_t ni = b.points.size[0], nj = b.points.size[1];
+    for (std::size_t i = 0; i < ni; ++i) {
+        b.points.data[b.points.index(i, 0)] = i_min.points[i];
+        b.points.data[b.points.index(i, nj - 1)] = i_max.points[i];
+    }
+    for (std::size_t j = 0; j < nj; ++j) {
+        b.points.data[b.points.index(0, j)] = j_min.points[j];
+        b.points.data[b.points.index(ni - 1, j)] = j_max.points[j];
+    }
+}
+
+static discrete::Mesh buildStrip(std::size_t nblocks, std::size_t ni, std::size_t nj) {
+    const double A = 0.1, two_pi = 2 * M_PI;
+    const auto t = clustering::create(clustering::Uniform{}, nj);
+    const auto s = clustering::create(clustering::Uniform{}, ni);
+    auto curve = [&](std::size_t k) {
+        std::vector<Vec2d> c(nj);
+        for (std::size_t j = 0; j < nj; ++j) c[j] = Vec2d{{t[j], static_cast<double>(k) + A * (1.0 - 2.0 * static_cast<double>(k) / static_cast<double>(nblocks)) * std::sin(two_pi * t[j])}};
+        c[0] = Vec2d{{0.0, static_cast<double>(k)}};
+        c[nj - 1] = Vec2d{{1.0, static_cast<double>(k)}};
+        return c;
+    };
+    discrete::Mesh mesh;
+    for (std::size_t k = 0; k < nblocks; ++k) {
+        const auto c0 = curve(k), c1 = curve(k + 1);
+        std::vector<Vec2d> left(ni), right(ni);
+        for (std::size_t i = 0; i < ni; ++i) {
+            left[i] = Vec2d{{0.0, static_cast<double>(k) + s[i]}};
+            right[i] = Vec2d{{1.0, static_cast<double>(k) + s[i]}};
+        }
+        left[0] = c0[0]; left[ni - 1] = c1[0];
+        right[0] = c0[nj - 1]; right[ni - 1] = c1[nj - 1];
+        const Edge i_min = uniformEdge(left), i_max = uniformEdge(right), j_min = uniformEdge(c0), j_max = uniformEdge(c1);
+        Block2d b = Block2d::init(i_min, i_max, j_min, j_max);
+        snap(b, i_min, i_max, j_min, j_max);
+        mesh.addBlock("block_" + std::to_string(k), std::move(b));
+    }
+    for (std::size_t k = 0; k + 1 < nblocks; ++k)
+        mesh.connections.push_back(boundary::Connection{{boundary::Range{k, boundary::Side::j_max, 0, nj - 1}, boundary::Range{k + 1, boundary::Side::j_min, 0, nj - 1}}, std::nullopt});
+    return mesh;
+}
+
+static discrete::Mesh buildSingle(std::size_t ni, std::size_t nj) {
+    const double A = 0.1, two_pi = 2 * M_PI;
+    const auto s = clustering::create(clustering::Uniform{}, ni);
+    const auto t = clustering::create(clustering::Uniform{}, nj);
+    std::vector<Vec2d> lo(ni), up(ni), le(nj), ri(nj);
+    for (std::size_t i = 0; i < ni; ++i) {
+        lo[i] = Vec2d{{s[i], A * std::sin(two_pi * s[i])}};
+        up[i] = Vec2d{{s[i], 1.0 - A * std::sin(two_pi * s[i])}};
+    }
+    for (std::size_t j = 0; j < nj; ++j) {
+        le[j] = Vec2d{{0.0, t[j]}};
+        ri[j] = Vec2d{{1.0, t[j]}};
+    }
+    lo[0] = Vec2d{{0, 0}}; lo[ni - 1] = Vec2d{{1, 0}};
+    up[0] = Vec2d{{0, 1}}; up[ni - 1] = Vec2d{{1, 1}};
+    const Edge i_min = uniformEdge(lo), i_max = uniformEdge(up), j_min = uniformEdge(le), j_max = uniformEdge(ri);
+    discrete::Mesh mesh;
+    Block2d b = Block2d::init(i_min, i_max, j_min, j_max);
+    snap(b, i_min, i_max, j_min, j_max);
+    mesh.addBlock("block", std::move(b));
+    return mesh;
+}
+
+int main(int argc, char** argv) {
+    try {
+        if (argc < 5) {
+            std::fprintf(stderr, "usage: %s strip <nblocks> <ni> <nj> <iterations> [relax|bicgstab] [dump.bin]\n       %s single <ni> <nj> <iterations> [relax|bicgstab] [dump.bin]\n", argv[0], argv[0]);
+            return 2;
+        }
+        int a = 2;
+        discrete::Mesh mesh;
+        if (std::strcmp(argv[1], "strip") == 0) {
+            const std::size_t nb = std::strtoull(argv[a++], nullptr, 10), ni = std::strtoull(argv[a++], nullptr, 10), nj = std::strtoull(argv[a++], nullptr, 10);
+            mesh = buildStrip(nb, ni, nj);
+        } else {
+            const std::size_t ni = std::strtoull(argv[a++], nullptr, 10), nj = std::strtoull(argv[a++], nullptr, 10);
+            mesh = buildSingle(ni, nj);
+        }
+        const std::size_t iterations = std::strtoull(argv[a++], nullptr, 10);
+        smoothing::solver::Option opt;
+        if (a < argc && std::strcmp(argv[a], "relax") == 0) opt.inner = TM_INNER_RELAX;
+        if (a < argc && (std::strcmp(argv[a], "relax") == 0 || std::strcmp(argv[a], "bicgstab") == 0)) ++a;
+        opt.rtol = 1e-13;
+        opt.max_inner = 5000;
+        const tm_stats st = smoothing::smooth::mesh(mesh, iterations, opt, smoothing::wall_control_function::Algorithm::laplace());
+        // the reference's log lines (smooth.zig:105, 137, 159)
+        std::printf("info(smoothing): iteration: %llu\n", static_cast<unsigned long long>(st.outer_iterations ? st.outer_iterations - 1 : 0));
+        std::printf("info(smoothing): \tresidual: %.17g\n", st.last_residual);
+        std::printf("info(smoothing): elapsed time for smoothing: %.2f s\n", st.seconds);
+        std::printf("inner_iterations %llu operator_sweeps %llu not_converged %d scaled_residual_rms %.3e\n", static_cast<unsigned long long>(st.inner_iterations),
+                    static_cast<unsigned long long>(st.operator_sweeps), st.not_converged, st.scaled_residual_rms);
+        if (a < argc) {
+            std::FILE* f = std::fopen(argv[a], "wb");
+            if (!f) throw Error(TM_E_ARG, "cannot open dump file");
+            for (const auto& b : mesh.blocks) std::fwrite(b.points.data.data(), sizeof(Vec2d), b.points.data.size(), f);
+            std::fclose(f);
+        }
+        return 0;
+    } catch (const core::Error& e) {
+        std::fprintf(stderr, "error(%d): %s\n", e.code, e.what());
+        return 1;
+    }
+}
