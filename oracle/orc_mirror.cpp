@@ -49,7 +49,8 @@ static inline Vec2d mirror_row(int mode, bool has_pq, Vec2d m_l, Vec2d m_c, Vec2
     const Float tx = sx * rinv, ty = sy * rinv;
     if (mode == MIRROR_SCALED) return vinit(tx, ty);
     if (mode == MIRROR_RESID) return vinit(-tx, -ty);
-    return vinit(std::fma(omega, -tx, c_c.data[0]), std::fma(omega, -ty, c_c.data[1]));
+    const Float dx = omega * (-tx), dy = omega * (-ty);   // the displacement of this sweep (kept unfused like the device)
+    return vinit(c_c.data[0] + dx, c_c.data[1] + dy);
 }
 
 // interior rows of one block: out(i,j) = row(in; coefficients from xk, pq); perimeter of `out` untouched

@@ -1,0 +1,104 @@
+"""SURVEY "next" row N1: the O4H blocking (templates/O4H.py), splines, csv reader and JSON front door, host side.
+BASELINE.json configs[0] (T106, CPU plumbing) and configs[2] (LS89, all blocks on one GPU).
+
+CPU: the reference's own KATs for csv / spline; block sizes; the reference-faithful oracle run of the JSON as written.
+GPU: TFI of all 8 blocks bit-exact vs the oracle; smoothing (Laplace and `white`) vs the exact-solve oracle."""
+import os
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.conftest import OracleMesh, mesh_flat, oracle_tfi
+from turbomesh_amd import csv as tcsv
+from turbomesh_amd import spline
+from turbomesh_amd.input import Input
+from turbomesh_amd.smoothing import smooth, solver, wall_control_function as wcf
+
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+SIZES = {   # SURVEY.md section 8 (derived from O4H.zig:71-74, 129-419 and the two JSONs)
+    "T106": [(221, 41), (121, 41), (11, 41), (11, 51), (121, 41), (161, 11), (21, 91), (11, 131)],
+    "LS89": [(381, 41), (161, 41), (6, 131), (11, 51), (116, 41), (266, 11), (21, 181), (11, 241)],
+}
+
+
+def load(name, tfi):
+    inp = Input.parse(open(os.path.join(GOLD, "examples", name, name + ".json")).read())
+    geom = inp.geometry(GOLD)
+    return inp, inp.template.run(geom, tfi=tfi)
+
+
+def test_csv_reference_kat():
+    d = tcsv.parseCsvIntoVec2d(os.path.join(GOLD, "examples", "T106", "T106_ps.dat"))   # csv.zig:59-67
+    assert d[0, 0] == 1.127030384 and d[0, 1] == -0.047185256
+    assert d[-1, 0] == 1.047805900 and d[-1, 1] == 0.000076595
+
+
+def test_spline_reference_kats():
+    s = spline.FittingSpline([[0, 0], [0.5, 0.5], [1, 1], [2, 2], [3, 3], [4, 4]])   # spline.zig:235-262
+    v = s.interpolate([0.0, 0.125, 0.25, 0.5, 0.75, 1.0])
+    assert np.abs(v - np.array([[0, 0], [0.5, 0.5], [1, 1], [2, 2], [3, 3], [4, 4]])).max() < 1e-9
+    assert abs(s.integrate() - np.sqrt(2.0) * 4.0) < 1e-9
+    s = spline.FittingSpline([[0, 0], [1, 0.5], [2, 1.5], [2.5, 3.0]])                 # spline.zig:264-287
+    v = s.interpolate([0.0, 0.5, 1.0])
+    assert v[0, 0] <= v[1, 0] <= v[2, 0]
+    assert np.abs(v[0] - [0, 0]).max() < 1e-9 and np.abs(v[2] - [2.5, 3.0]).max() < 1e-9
+    assert abs(spline.FittingSpline([[0, 0], [0, 3.0]]).integrate() - 3.0) < 1e-9      # spline.zig:289-302
+
+
+@pytest.mark.parametrize("name", ["T106", "LS89"])
+def test_o4h_block_sizes_and_topology(name):
+    inp, mesh = load(name, oracle_tfi)
+    assert [b.points.size for b in mesh.blocks] == SIZES[name]
+    assert len(mesh.connections) == 21 and sum(c.periodicity is not None for c in mesh.connections) == 3
+    assert len(mesh.boundary_conditions) == 2 and inp.iterations == 10
+    om = OracleMesh(mesh)
+    s = oracle.System(om, ("white", 1e-6, 1.570796327))   # connectionDataCheck (1e-15), row kinds, junctions, CSR pattern
+    rows = smooth.plan_rows(mesh)
+    assert np.array_equal(rows["kind"], s.boundary_kind)
+    assert np.bincount(s.boundary_kind, minlength=5)[oracle.KIND_LAPLACIAN] == 12
+    p, ci = s.lhs_p, s.lhs_i
+    for k, g in enumerate(rows["row"]):
+        assert np.array_equal(ci[p[g]:p[g + 1]], rows["cols"][k, :rows["ncols"][k]])
+
+
+def test_config1_t106_json_as_written_on_the_cpu_oracle():
+    # BASELINE configs[0]: 10 iterations, GMRES + ILU(0), white control function -- the reference's CPU path, restated
+    inp, mesh = load("T106", oracle_tfi)
+    om = OracleMesh(mesh)
+    w = inp.wall_control_function.white
+    st = oracle.smooth_mesh(om, inp.iterations, solver=oracle.SOLVER_GMRES, preconditioner=oracle.PRECOND_ILU0, control=("white", w.ds_target, w.theta_target))
+    assert st.outer_iterations == 10 and st.not_converged == 0
+    assert st.residual_history[-1] < 1e-4 * st.residual_history[0] and np.isfinite(om.flat()).all()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["T106", "LS89"])
+def test_gpu_o4h_tfi_and_smoothing(name):
+    inp, mesh = load(name, None)              # Block2d.init -> TFI on the GPU
+    _, mesh_cpu = load(name, oracle_tfi)
+    for a, b in zip(mesh.blocks, mesh_cpu.blocks):
+        assert a.points.data.tobytes() == b.points.data.tobytes()
+    # Laplace control function: 2 Picard iterations vs the exact-solve oracle
+    om = OracleMesh(mesh)
+    hist, _ = oracle.picard_exact(om, 2)
+    with smooth.Smoother(mesh, solver.Option.hip(rtol=1e-13, max_inner=20000)) as sm:
+        st = sm.iterate(2)
+        sm.download()
+    assert st["not_converged"] == 0
+    rms = float(np.sqrt(np.mean((mesh_flat(mesh) - om.flat()) ** 2)))
+    assert rms <= 1e-10, rms
+    assert st["last_residual"] == pytest.approx(hist[-1], rel=1e-5)
+
+
+@pytest.mark.gpu
+def test_gpu_t106_white_control_function():
+    inp, mesh = load("T106", None)
+    w = inp.wall_control_function.white
+    om = OracleMesh(mesh)
+    oracle.picard_exact(om, 3, control=("white", w.ds_target, w.theta_target))
+    with smooth.Smoother(mesh, solver.Option.hip(rtol=1e-13, max_inner=20000), wcf.Algorithm(wcf.White(w.ds_target, w.theta_target))) as sm:
+        st = sm.iterate(3)
+        sm.download()
+    rms = float(np.sqrt(np.mean((mesh_flat(mesh) - om.flat()) ** 2)))
+    assert rms <= 1e-9, (rms, st)   # (P,Q) go through device acos/atan2: looser than the Laplace bar

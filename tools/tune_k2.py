@@ -48,9 +48,9 @@ def timed(fn, reps=40):
 a = torch.empty(n * n * 2, dtype=torch.float64, device="cuda").normal_()
 b = torch.empty_like(a)
 L = _capi.lib()
-for rows, unroll, pipe, nt in ((64, 4, 0, 1), (64, 2, 0, 1), (32, 4, 1, 1)):
+for rows, unroll, pipe, nt in ((64, 3, 0, 1), (32, 6, 0, 1)):
     L.tm_tune_apply(rows, unroll, pipe, nt)
-    for mode, label in ((4, "diag_copy"), (5, "diag_sum9"), (6, "diag_nostore(math+loads)"), (7, "diag_noload(math+stores)")):
+    for mode, label in ((4, "diag_copy"), (5, "diag_sum9"), (6, "diag_nostore(math+loads)"), (7, "diag_noload(math+stores)"), (8, "diag_math_only")):
         us = timed(lambda: L.tm_diag_apply(a.data_ptr(), b.data_ptr(), n, n, mode, None))
         print(os.environ.get("TM_TUNE_TAG", ""), label, "rows", rows, "U", unroll, "pipe", pipe, "nt", nt, f"{us:.1f} us (back-to-back launches incl. gaps)", f"{32.0 * n * n / us / 1e3:.0f} GB/s", flush=True)
     us = timed(lambda: L.tm_dev_relax_sweep(a.data_ptr(), b.data_ptr(), n, n, 1.0, None, 0, None, None))

@@ -17,7 +17,8 @@ enum ApplyMode : int {
     MODE_DIAG_COPY = 4,   // out = in
     MODE_DIAG_SUM9 = 5,   // out = plain sum of the 9 neighbours (loads, halo, lane shifts; no coefficients)
     MODE_DIAG_NOSTORE = 6,   // full relax arithmetic, all loads, NO store (result folded into the partial sums)
-    MODE_DIAG_NOLOAD = 7     // full relax arithmetic and stores, rows are NOT re-loaded (window reused)
+    MODE_DIAG_NOLOAD = 7,    // full relax arithmetic and stores, rows are NOT re-loaded (window reused)
+    MODE_DIAG_MATH = 8       // full relax arithmetic only: no loads, no stores
 };
 // ---- fused partial reductions written per workgroup (x and y components separately)
 enum DotMode : int {

@@ -131,10 +131,9 @@ __device__ __forceinline__ void accumulate(double (&acc)[MAX_PARTIALS], double2 
     } else if (DOT == DOT_OUT2) {
         acc[0] += out.x * out.x;
         acc[1] += out.y * out.y;
-    } else if (DOT == DOT_DELTA) {
-        const double dx = out.x - in_self.x, dy = out.y - in_self.y;
-        acc[0] += dx * dx;
-        acc[1] += dy * dy;
+    } else if (DOT == DOT_DELTA) {   // interior rows pass the displacement in `aux`
+        acc[0] = fma(aux.x, aux.x, acc[0]);
+        acc[1] = fma(aux.y, aux.y, acc[1]);
     }
 }
 
@@ -154,7 +153,7 @@ __device__ __forceinline__ void accumulate(double (&acc)[MAX_PARTIALS], double2 
 template <int MODE, bool HAS_PQ>
 __device__ __forceinline__ double2 winslow_row(double2 m_l, double2 m_c, double2 m_r, double2 c_l, double2 c_c, double2 c_r, double2 p_l,
                                                double2 p_c, double2 p_r, double2 xm, double2 xp, double2 xl, double2 xr, double P, double Q,
-                                               double omega) {
+                                               double omega, double2& delta) {
     const double dxi_x = xp.x - xm.x, dxi_y = xp.y - xm.y;
     const double det_x = xr.x - xl.x, det_y = xr.y - xl.y;
     const double G11 = fma(dxi_x, dxi_x, dxi_y * dxi_y);
@@ -186,7 +185,8 @@ __device__ __forceinline__ double2 winslow_row(double2 m_l, double2 m_c, double2
     const double tx = sx * rinv, ty = sy * rinv;          // (D^-1 A w)_row
     if (MODE == MODE_SCALED) return make_double2(tx, ty);
     if (MODE == MODE_RESID) return make_double2(-tx, -ty);   // b = 0 on interior rows
-    return make_double2(fma(omega, -tx, c_c.x), fma(omega, -ty, c_c.y));   // MODE_RELAX
+    delta = make_double2(omega * (-tx), omega * (-ty));       // MODE_RELAX: the displacement of this sweep
+    return make_double2(c_c.x + delta.x, c_c.y + delta.y);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -194,14 +194,14 @@ __device__ __forceinline__ double2 winslow_row(double2 m_l, double2 m_c, double2
 //     BiCGStab.zig:424-435 mat-vec), matrix-free, factored row evaluation (winslow_row)
 // ------------------------------------------------------------------------------------------
 static int g_rows_per_chunk = 64;   // tunable (tm_tune_apply)
-static int g_unroll = 4;
-static int g_pipe = 0;
+static int g_unroll = 3;   // rows per load group: 3 or 6
 static int g_nt = 1;
 
 typedef double d2v __attribute__((ext_vector_type(2)));
 
-template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool PIPE, bool NT>
+template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool NT>
 __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, int nRC) {
+    static_assert(U % 3 == 0, "the 3-row window rotates by renaming: the row group must be a multiple of 3");
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     // XCD-aware tile order: physical workgroup b runs on XCD b%8; give each XCD a contiguous
@@ -220,6 +220,7 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
     const bool edge_lane = (lane == 0) || (lane == 63);
     const int hcol = (lane == 0) ? max(j0 - 1, 0) : min(j0 + 64, nj - 1);
     const bool valid_col = (j >= 1) && (j <= nj - 2);
+    const bool full_wave = (j0 >= 1) && (j0 + 63 <= nj - 2);   // wave-uniform: every lane owns an output column
     const int i0 = 1 + rc * RI;
     const int i1 = min(i0 + RI, ni - 1);   // output rows [i0, i1)
 
@@ -232,20 +233,24 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
             h = make_double2(0.0, 0.0);   // NOT `h = c`: that copy would force a vmcnt(0) wait right behind every row load
             if (edge_lane) h = rp[hcol];
         };
-        // 3-row window of the vector: m = row i-1, c = row i, p = row i+1; l/r = columns j-1/j+1
-        double2 wm_c, wm_h, wc_c, wc_h;
-        load_row(a.in, i0 - 1, wm_c, wm_h);
-        load_row(a.in, i0, wc_c, wc_h);
-        double2 wm_l = lane_prev(wm_h, wm_c), wm_r = lane_next(wm_h, wm_c);
-        double2 wc_l = lane_prev(wc_h, wc_c), wc_r = lane_next(wc_h, wc_c);
-        // frozen coordinates when they are a different array: centre of rows i-1, i+1; l/r of row i
-        double2 xm_c = wm_c, xc_c = wc_c, xc_l = wc_l, xc_r = wc_r;
-        if (!FIELD) {
-            double2 t_h;
-            load_row(a.xk, i0 - 1, xm_c, t_h);
-            load_row(a.xk, i0, xc_c, t_h);
-            xc_l = lane_prev(t_h, xc_c);
-            xc_r = lane_next(t_h, xc_c);
+        // 3-row window of the vector, rotating by index: slot (r % 3) holds row i0-1+r; l/r = columns j-1/j+1
+        double2 Wc[3], Wl[3], Wr[3];
+        double2 Xc[3], Xl = make_double2(0.0, 0.0), Xr = make_double2(0.0, 0.0);   // frozen coordinates when they are a different array
+        {
+            double2 h0, h1;
+            load_row(a.in, i0 - 1, Wc[0], h0);
+            load_row(a.in, i0, Wc[1], h1);
+            Wl[0] = lane_prev(h0, Wc[0]); Wr[0] = lane_next(h0, Wc[0]);
+            Wl[1] = lane_prev(h1, Wc[1]); Wr[1] = lane_next(h1, Wc[1]);
+            Wc[2] = Wl[2] = Wr[2] = make_double2(0.0, 0.0);
+            Xc[0] = Xc[1] = Xc[2] = make_double2(0.0, 0.0);
+            if (!FIELD) {
+                double2 t_h;
+                load_row(a.xk, i0 - 1, Xc[0], t_h);
+                load_row(a.xk, i0, Xc[1], t_h);
+                Xl = lane_prev(t_h, Xc[1]);
+                Xr = lane_next(t_h, Xc[1]);
+            }
         }
 
         struct Group {
@@ -255,9 +260,9 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
 #pragma unroll
             for (int u = 0; u < U; ++u) {
                 const int prow = min(ib + u + 1, ni - 1);
-                if (MODE == MODE_DIAG_NOLOAD) {
-                    g.pc[u] = wc_c;
-                    g.ph[u] = wc_h;
+                if (MODE == MODE_DIAG_NOLOAD || MODE == MODE_DIAG_MATH) {
+                    g.pc[u] = Wc[1];
+                    g.ph[u] = Wl[1];
                 } else
                     load_row(a.in, prow, g.pc[u], g.ph[u]);
                 if (!FIELD) load_row(a.xk, prow, g.xpc[u], g.xph[u]);
@@ -266,31 +271,36 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
                 if (DOT == DOT_AUX) g.auxv[u] = a.aux[cur];
             }
         };
-        auto compute_group = [&](int ib, const Group& g) {
+        // PRED = false: full wave and full row group -> no exec masking around the arithmetic and the store
+        auto compute_group = [&](int ib, const Group& g, auto pred_tag) {
+            constexpr bool PRED = decltype(pred_tag)::value;
 #pragma unroll
             for (int u = 0; u < U; ++u) {
+                const int M = u % 3, C = (u + 1) % 3, P3 = (u + 2) % 3;   // window slots of rows i-1, i, i+1
                 const int row = ib + u;
-                const double2 wp_c = g.pc[u];
-                const double2 wp_l = lane_prev(g.ph[u], g.pc[u]), wp_r = lane_next(g.ph[u], g.pc[u]);
+                Wc[P3] = g.pc[u];
+                Wl[P3] = lane_prev(g.ph[u], g.pc[u]);
+                Wr[P3] = lane_next(g.ph[u], g.pc[u]);
+                if (!FIELD) Xc[P3] = g.xpc[u];
 
                 const double P = HAS_PQ ? g.pqv[u].x : 0.0, Q = HAS_PQ ? g.pqv[u].y : 0.0;
-                double2 o;
+                double2 o, delta = make_double2(0.0, 0.0);
                 if (MODE == MODE_DIAG_COPY) {
-                    o = wc_c;
+                    o = Wc[C];
                 } else if (MODE == MODE_DIAG_SUM9) {
-                    o.x = wm_l.x + wm_c.x + wm_r.x + wc_l.x + wc_c.x + wc_r.x + wp_l.x + wp_c.x + wp_r.x;
-                    o.y = wm_l.y + wm_c.y + wm_r.y + wc_l.y + wc_c.y + wc_r.y + wp_l.y + wp_c.y + wp_r.y;
-                } else if (MODE == MODE_DIAG_NOSTORE || MODE == MODE_DIAG_NOLOAD) {
-                    o = winslow_row<MODE_RELAX, HAS_PQ>(wm_l, wm_c, wm_r, wc_l, wc_c, wc_r, wp_l, wp_c, wp_r, wm_c, wp_c, wc_l, wc_r, P, Q, a.omega);
+                    o.x = Wl[M].x + Wc[M].x + Wr[M].x + Wl[C].x + Wc[C].x + Wr[C].x + Wl[P3].x + Wc[P3].x + Wr[P3].x;
+                    o.y = Wl[M].y + Wc[M].y + Wr[M].y + Wl[C].y + Wc[C].y + Wr[C].y + Wl[P3].y + Wc[P3].y + Wr[P3].y;
+                } else if (MODE == MODE_DIAG_NOSTORE || MODE == MODE_DIAG_NOLOAD || MODE == MODE_DIAG_MATH) {
+                    o = winslow_row<MODE_RELAX, HAS_PQ>(Wl[M], Wc[M], Wr[M], Wl[C], Wc[C], Wr[C], Wl[P3], Wc[P3], Wr[P3], Wc[M], Wc[P3], Wl[C], Wr[C], P, Q, a.omega, delta);
                 } else if (FIELD) {
-                    o = winslow_row<MODE, HAS_PQ>(wm_l, wm_c, wm_r, wc_l, wc_c, wc_r, wp_l, wp_c, wp_r, wm_c, wp_c, wc_l, wc_r, P, Q, a.omega);
+                    o = winslow_row<MODE, HAS_PQ>(Wl[M], Wc[M], Wr[M], Wl[C], Wc[C], Wr[C], Wl[P3], Wc[P3], Wr[P3], Wc[M], Wc[P3], Wl[C], Wr[C], P, Q, a.omega, delta);
                 } else {
-                    o = winslow_row<MODE, HAS_PQ>(wm_l, wm_c, wm_r, wc_l, wc_c, wc_r, wp_l, wp_c, wp_r, xm_c, g.xpc[u], xc_l, xc_r, P, Q, a.omega);
+                    o = winslow_row<MODE, HAS_PQ>(Wl[M], Wc[M], Wr[M], Wl[C], Wc[C], Wr[C], Wl[P3], Wc[P3], Wr[P3], Xc[M], Xc[P3], Xl, Xr, P, Q, a.omega, delta);
                 }
-                if (MODE == MODE_DIAG_NOSTORE) {
+                if (MODE == MODE_DIAG_NOSTORE || MODE == MODE_DIAG_MATH) {
                     acc[0] += o.x;
                     acc[1] += o.y;
-                } else if (row < i1 && valid_col) {
+                } else if (!PRED || (row < i1 && valid_col)) {
                     double2* dst = a.out + static_cast<size_t>(row) * nj + j;
                     if (NT) {
                         d2v ov;
@@ -300,44 +310,30 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
                     } else {
                         *dst = o;
                     }
-                    accumulate<DOT>(acc, wc_c, o, (DOT == DOT_AUX) ? g.auxv[u] : o);
+                    accumulate<DOT>(acc, Wc[C], o, (DOT == DOT_AUX) ? g.auxv[u] : ((DOT == DOT_DELTA) ? delta : o));
                 }
-                // slide the window down one row
-                wm_c = wc_c; wm_l = wc_l; wm_r = wc_r;
-                wc_c = wp_c; wc_l = wp_l; wc_r = wp_r;
-                if (!FIELD) {
-                    xm_c = xc_c;
-                    xc_c = g.xpc[u];
-                    xc_l = lane_prev(g.xph[u], g.xpc[u]);
-                    xc_r = lane_next(g.xph[u], g.xpc[u]);
+                if (!FIELD) {   // l/r of the frozen field for the next row (= row i+1)
+                    Xl = lane_prev(g.xph[u], g.xpc[u]);
+                    Xr = lane_next(g.xph[u], g.xpc[u]);
                 }
             }
         };
 
-        if (PIPE) {   // software pipeline: the loads of the next row group are in flight while this one is computed
-            Group A, B;
-            int ib = i0;
-            load_group(ib, A);
-            while (true) {
-                const bool hasB = ib + U < i1;
-                if (hasB) load_group(ib + U, B);
-                compute_group(ib, A);
-                if (!hasB) break;
-                const bool hasA = ib + 2 * U < i1;
-                if (hasA) load_group(ib + 2 * U, A);
-                compute_group(ib + U, B);
-                if (!hasA) break;
-                ib += 2 * U;
-            }
-        } else {
-            for (int ib = i0; ib < i1; ib += U) {
+        int ib = i0;
+        if (full_wave) {
+            for (; ib + U <= i1; ib += U) {
                 Group g;
                 load_group(ib, g);
-                compute_group(ib, g);
+                compute_group(ib, g, std::false_type{});
             }
         }
+        for (; ib < i1; ib += U) {   // partial waves (block edges) and the row tail
+            Group g;
+            load_group(ib, g);
+            compute_group(ib, g, std::true_type{});
+        }
     }
-    if (MODE == MODE_DIAG_NOSTORE && acc[0] + acc[1] == 123.456) a.out[0] = make_double2(acc[0], acc[1]);   // keep the arithmetic live
+    if ((MODE == MODE_DIAG_NOSTORE || MODE == MODE_DIAG_MATH) && acc[0] + acc[1] == 123.456) a.out[0] = make_double2(acc[0], acc[1]);   // keep the arithmetic live
     if (DOT != DOT_NONE) block_partials<256>(acc, a.partials + static_cast<size_t>(bid) * MAX_PARTIALS);
 }
 
@@ -420,7 +416,8 @@ __global__ __launch_bounds__(256) void k_apply_ring(ApplyBlock a, int RI, int nS
             dma_row(q + R, slot);   // refill the slot (glds16 waits lgkmcnt(0) first)
             if (q >= i0 + 1) {
                 const int row = q - 1;
-                const double2 o = winslow_row<MODE, false>(m_l, m_c, m_r, c_l, c_c, c_r, p_l, p_c, p_r, m_c, p_c, c_l, c_r, 0.0, 0.0, a.omega);
+                double2 delta = make_double2(0.0, 0.0);
+                const double2 o = winslow_row<MODE, false>(m_l, m_c, m_r, c_l, c_c, c_r, p_l, p_c, p_r, m_c, p_c, c_l, c_r, 0.0, 0.0, a.omega, delta);
                 if (valid_col) {
                     double2* dst = a.out + static_cast<size_t>(row) * nj + j;
                     if (NT) {
@@ -431,7 +428,7 @@ __global__ __launch_bounds__(256) void k_apply_ring(ApplyBlock a, int RI, int nS
                     } else {
                         *dst = o;
                     }
-                    accumulate<DOT>(acc, c_c, o, o);
+                    accumulate<DOT>(acc, c_c, o, (DOT == DOT_DELTA) ? delta : o);
                 }
             }
             m_l = c_l; m_c = c_c; m_r = c_r;
@@ -483,19 +480,11 @@ int apply_block_nwg(int ni, int nj) {
 template <int MODE, int DOT, bool FIELD, bool HAS_PQ>
 static hipError_t launch_apply_u(const ApplyBlock& a, int RI, int nSG, int nRC, hipStream_t st) {
     const dim3 grid(nSG * nRC), block(256);
-#define TM_K2(U_, P_, N_) hipLaunchKernelGGL((k_apply<MODE, DOT, FIELD, HAS_PQ, U_, P_, N_>), grid, block, 0, st, a, RI, nSG, nRC)
-    const int key = g_unroll * 100 + (g_pipe ? 10 : 0) + (g_nt ? 1 : 0);
-    switch (key) {
-        case 100: TM_K2(1, false, false); break;
-        case 110: TM_K2(1, true, false); break;
-        case 200: TM_K2(2, false, false); break;
-        case 201: TM_K2(2, false, true); break;
-        case 211: TM_K2(2, true, true); break;
-        case 400: TM_K2(4, false, false); break;
-        case 401: TM_K2(4, false, true); break;
-        case 410: TM_K2(4, true, false); break;
-        case 411: TM_K2(4, true, true); break;
-        default: TM_K2(2, true, false); break;   // 210
+#define TM_K2(U_, N_) hipLaunchKernelGGL((k_apply<MODE, DOT, FIELD, HAS_PQ, U_, N_>), grid, block, 0, st, a, RI, nSG, nRC)
+    if (g_unroll >= 6) {
+        if (g_nt) TM_K2(6, true); else TM_K2(6, false);
+    } else {
+        if (g_nt) TM_K2(3, true); else TM_K2(3, false);
     }
 #undef TM_K2
     return hipGetLastError();
@@ -532,14 +521,15 @@ hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_
     if (mode == MODE_DIAG_SUM9) return launch_apply_md<MODE_DIAG_SUM9, DOT_NONE>(a, RI, nSG, nRC, st);
     if (mode == MODE_DIAG_NOSTORE) return launch_apply_md<MODE_DIAG_NOSTORE, DOT_NONE>(a, RI, nSG, nRC, st);
     if (mode == MODE_DIAG_NOLOAD) return launch_apply_md<MODE_DIAG_NOLOAD, DOT_NONE>(a, RI, nSG, nRC, st);
+    if (mode == MODE_DIAG_MATH) return launch_apply_md<MODE_DIAG_MATH, DOT_NONE>(a, RI, nSG, nRC, st);
     return hipErrorInvalidValue;
 }
 
 void tune_ring(int depth) { g_ring = depth; }
 void tune_apply(int rows, int unroll, int pipe, int nt) {
     if (rows > 0) g_rows_per_chunk = rows;
-    if (unroll == 1 || unroll == 2 || unroll == 4) g_unroll = unroll;
-    if (pipe >= 0) g_pipe = pipe;
+    if (unroll > 0) g_unroll = unroll;
+    (void)pipe;
     if (nt >= 0) g_nt = nt;
 }
 
@@ -625,7 +615,7 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const d
         o.x = row_out<MODE>(sx, rhs_x, diag_x, w_self.x, om);
         o.y = row_out<MODE>(sy, rhs_y, diag_y, w_self.y, om);
         out[row] = o;
-        accumulate<DOT>(acc, w_self, o, (DOT == DOT_AUX) ? aux[row] : o);
+        accumulate<DOT>(acc, w_self, o, (DOT == DOT_AUX) ? aux[row] : ((DOT == DOT_DELTA) ? make_double2(o.x - w_self.x, o.y - w_self.y) : o));
     }
     if (DOT != DOT_NONE) block_partials<EDGE_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
