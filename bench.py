@@ -63,7 +63,7 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--n", type=int, default=4096, help="block edge (nodes); 4096 is the BASELINE config")
+    ap.add_argument("--size", dest="n", type=int, default=4096, help="block edge (nodes); 4096 is the BASELINE config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (RCCL hooks) even with one rank")
     ap.add_argument("--rows", type=int, default=0, help="K2 rows per chunk (tuning)")
@@ -88,6 +88,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
+    if os.environ.get("TM_BENCH_SAME_DEVICE"):   # rehearsal of the multi-rank path on a one-GPU box
+        local_rank = 0
     torch.cuda.set_device(local_rank)
 
     from turbomesh_amd import _capi, configs
@@ -105,7 +107,11 @@ def main():
         dist = dist_mod
         if "MASTER_ADDR" not in os.environ:   # --force-dist without a launcher
             os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", "29533"
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        backend = os.environ.get("TM_BENCH_BACKEND", "nccl")   # "gloo" = rehearsal transport (halo rows staged through the host)
+        if backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend, rank=rank, world_size=world)
         from turbomesh_amd import distributed as tmd
 
         mesh = tmd.strip_for_rank(world, rank, n, n)                        # only the owned block carries coordinates
@@ -135,7 +141,7 @@ def main():
     sm.profile(False)
 
     if dist is not None:
-        tt = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     nodes_total = n * n * world
@@ -154,7 +160,7 @@ def main():
             except Exception:
                 traffic = None
         out = {
-            "metric": "nodes smoothed/sec (elliptic sweeps of the 4096^2 block) + achieved HBM GB/s",
+            "metric": f"nodes smoothed/sec (elliptic sweeps of the {n}^2 block) + achieved HBM GB/s",
             "value": value, "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",

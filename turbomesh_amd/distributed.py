@@ -78,7 +78,19 @@ class HaloExchanger:
                 ops.append(dist.P2POp(dist.isend, send[so:so + sc], peer, self.group))
         return ops
 
+    def _staged(self, t):
+        """gloo has no CUDA point-to-point: device buffers are staged through the host (debug / rehearsal transport)."""
+        return t is not None and t.is_cuda and self.dist.get_backend(self.group) != "nccl"
+
     def start(self, send, recv):
+        if self._staged(send) or self._staged(recv):
+            self._recv_dev = recv
+            send = send.cpu() if send is not None else None   # synchronises the stream: the pack kernel has finished
+            recv = self._recv_host = (recv.cpu() if recv is not None else None)
+            self._works = [self.dist.batch_isend_irecv(self._build(send, recv))] if (send is not None or recv is not None) else []
+            self._works = [w for ws in self._works for w in ws]
+            return
+        self._recv_dev = None
         key = (send.data_ptr() if send is not None else 0, recv.data_ptr() if recv is not None else 0)
         ops = self._ops.get(key)
         if ops is None:
@@ -89,12 +101,20 @@ class HaloExchanger:
         for w in self._works:
             w.wait()   # NCCL: makes the current stream wait, the host does not block
         self._works = []
+        if getattr(self, "_recv_dev", None) is not None:
+            self._recv_dev.copy_(self._recv_host)
+            self._recv_dev = None
 
     def exchange(self, send, recv):
         self.start(send, recv)
         self.wait()
 
     def allreduce(self, t):
+        if self._staged(t):
+            h = t.cpu()
+            self.dist.all_reduce(h, op=self.dist.ReduceOp.SUM, group=self.group)
+            t.copy_(h)
+            return
         self.dist.all_reduce(t, op=self.dist.ReduceOp.SUM, group=self.group)
 
 
