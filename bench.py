@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--unroll", type=int, default=0, help="K2 row unroll (tuning)")
     ap.add_argument("--pipe", type=int, default=-1, help="K2 software pipelining 0/1 (tuning)")
     ap.add_argument("--nt", type=int, default=-1, help="K2 non-temporal stores 0/1 (tuning)")
+    ap.add_argument("--single-sweep", action="store_true", help="one kernel pass per sweep (K2) instead of two sweeps per pass (K2x2)")
+    ap.add_argument("--fuse-rows", type=int, default=0, help="K2x2 rows per chunk (tuning)")
     args = ap.parse_args()
 
     # Libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on stdout, so everything
@@ -98,6 +100,10 @@ def main():
     if args.rows or args.unroll or args.pipe >= 0 or args.nt >= 0:
         _capi.lib().tm_tune_apply(args.rows, args.unroll, args.pipe, args.nt)
 
+    if args.fuse_rows:
+        _capi.lib().tm_tune_fuse(args.fuse_rows)
+    relax_opt = solver.Option.hip(inner=solver.Inner.relax, single_sweep=args.single_sweep)
+
     n = args.n
     dist = None
     hooks_obj = None
@@ -116,12 +122,12 @@ def main():
 
         mesh = tmd.strip_for_rank(world, rank, n, n)                        # only the owned block carries coordinates
         hooks_obj = tmd.TorchHooks(mesh, owner=list(range(world)), rank=rank, world=world,
-                                   option=solver.Option.hip(inner=solver.Inner.relax))
+                                   option=relax_opt)
         sm = hooks_obj.smoother
         workload = f"strip of {world} blocks {n}x{n}, one per GPU, interface rows exchanged by RCCL p2p every sweep"
     else:
         mesh = configs.single_block(n, n)                                   # TFI on the GPU (K1)
-        sm = smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax), stream=torch.cuda.current_stream().cuda_stream)
+        sm = smooth.Smoother(mesh, relax_opt, stream=torch.cuda.current_stream().cuda_stream)
         workload = f"single synthetic {n}x{n} block, TFI seed, Laplace control function, fixed boundary (SURVEY 8d config 2)"
 
     def barrier():
@@ -149,13 +155,16 @@ def main():
 
     if rank == 0:
         k2_avg_s = (k2_ms / 1e3) / max(1, k2_launches)
-        achieved = BYTES_PER_NODE * n * n / k2_avg_s / 1e9     # one K2 launch sweeps one block
+        sweeps_per_launch = st["operator_sweeps"] / max(1, k2_launches)   # one launch takes this rank's block through 1 (K2) or 2 (K2x2) sweeps
+        bytes_per_launch = BYTES_PER_NODE * n * n * sweeps_per_launch     # 32 B per node per sweep
+        achieved = bytes_per_launch / k2_avg_s / 1e9
+        fused = sweeps_per_launch > 1.5
         traffic = None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
         if os.path.exists(tpath):
             try:
                 tj = json.load(open(tpath))
-                if tj.get("n") == n:
+                if tj.get("n") == n and tj.get("kernel", "k_apply") == ("k_relax2" if fused else "k_apply"):
                     traffic = tj.get("hbm_bytes_per_launch")
             except Exception:
                 traffic = None
@@ -164,11 +173,14 @@ def main():
             "value": value, "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "nodes_per_gpu": n * n, "solver": "hip/relax (fused Jacobi elliptic sweep)", "omega": 1.0,
+            "config": {"workload": workload, "nodes_per_gpu": n * n, "solver": "hip/relax (fused Jacobi elliptic sweep" + (", two sweeps per kernel pass)" if fused else ")"), "omega": 1.0,
                        "residual_last": st["last_residual"], "whole_job_GBps_algorithmic": BYTES_PER_NODE * value / 1e9},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic, "kernel": "k_apply<RELAX,DELTA,field,laplace> (K2 winslow_apply)",
-                         "bytes_per_launch_algorithmic": BYTES_PER_NODE * n * n, "avg_launch_us": k2_avg_s * 1e6, "launches": k2_launches,
+                         "traffic": traffic,
+                         "kernel": "k_relax2<DELTA> (K2x2: two winslow sweeps per launch)" if fused else "k_apply<RELAX,DELTA,field,laplace> (K2 winslow_apply)",
+                         "sweeps_per_launch": sweeps_per_launch, "bytes_per_launch_algorithmic": bytes_per_launch,
+                         "hbm_GBps_measured_traffic": (traffic / k2_avg_s / 1e9) if traffic else None,
+                         "avg_launch_us": k2_avg_s * 1e6, "launches": k2_launches,
                          "timing": "hipEvent pairs around every K2 launch on the handle's stream, inside the timed region"},
         }
         if not args.no_cpu_baseline and world == 1:

@@ -105,6 +105,11 @@ enum {
                                 matrix-free BiCGStab on the row-equilibrated operator D^-1 A (replaces BiCGStab.zig:279-370) */
     TM_INNER_RELAX = 1       /* every outer iteration is ONE fused Jacobi elliptic sweep X <- X + omega D^-1 (b - A(X) X)   */
 };
+/* tm_solver_opt.flags */
+enum {
+    TM_OPT_SINGLE_SWEEP = 1  /* TM_INNER_RELAX: one kernel pass per sweep.  Default (bit clear): sweeps are taken two per pass
+                                where the blocks allow it (same arithmetic, bit-identical coordinates, half the HBM traffic) */
+};
 typedef struct tm_solver_opt {
     int32_t tag;             /* TM_SOLVER_* */
     int32_t inner;           /* TM_INNER_* */
@@ -112,7 +117,7 @@ typedef struct tm_solver_opt {
     double atol;             /* 0 -> 0 */
     uint64_t max_inner;      /* BiCGStab iteration cap per Picard solve; 0 -> 1000 (BiCGStab.zig:19) */
     uint32_t check_every;    /* host convergence poll interval in inner iterations; 0 -> 8 */
-    uint32_t _pad;
+    uint32_t flags;          /* TM_OPT_* bits; 0 = defaults */
     double omega;            /* relaxation factor of TM_INNER_RELAX; 0 -> 1.0 */
 } tm_solver_opt;
 

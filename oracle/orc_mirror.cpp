@@ -35,8 +35,9 @@ static inline Vec2d mirror_row(int mode, bool has_pq, Vec2d m_l, Vec2d m_c, Vec2
         bx = std::fma(hQ, c_r.data[0] - c_l.data[0], bx);
         by = std::fma(hQ, c_r.data[1] - c_l.data[1], by);
     }
-    const Float kx = (p_r.data[0] + m_l.data[0]) - (p_l.data[0] + m_r.data[0]);
-    const Float ky = (p_r.data[1] + m_l.data[1]) - (p_l.data[1] + m_r.data[1]);
+    // cross term from the per-row differences e = w(j+1) - w(j-1), which the device forms once per loaded row
+    const Float kx = (p_r.data[0] - p_l.data[0]) - (m_r.data[0] - m_l.data[0]);
+    const Float ky = (p_r.data[1] - p_l.data[1]) - (m_r.data[1] - m_l.data[1]);
     Float sx = G22 * ax, sy = G22 * ay;
     sx = std::fma(G11, bx, sx);
     sy = std::fma(G11, by, sy);

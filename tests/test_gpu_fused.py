@@ -1,0 +1,69 @@
+"""K2x2 (two Jacobi elliptic sweeps per kernel pass) against the one-sweep-per-pass path: same arithmetic in the
+same order, so the coordinates must agree BIT FOR BIT for every topology, block shape and sweep count (odd counts
+finish with one single sweep).  The single-sweep path itself is pinned bit-exactly to the oracle's mirror in
+tests/test_gpu_smooth.py / test_gpu_fullsize.py."""
+import numpy as np
+import pytest
+
+from tests.conftest import mesh_flat
+from tests.meshes import TOPOLOGIES
+from turbomesh_amd import configs
+from turbomesh_amd.smoothing import smooth, solver
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(builder, sweeps, single, omega=1.0, chunks=None):
+    mesh = builder()
+    opt = solver.Option.hip(inner=solver.Inner.relax, single_sweep=single, omega=omega)
+    with smooth.Smoother(mesh, opt) as sm:
+        st = None
+        for n in (chunks or [sweeps]):
+            st = sm.iterate(n)
+        sm.download()
+    return mesh_flat(mesh), st
+
+
+@pytest.mark.parametrize("name", list(TOPOLOGIES))
+@pytest.mark.parametrize("sweeps", [2, 5])
+def test_fused_pairs_equal_single_sweeps_on_every_topology(name, sweeps):
+    a, sa = _run(TOPOLOGIES[name], sweeps, single=True)
+    b, sb = _run(TOPOLOGIES[name], sweeps, single=False)
+    assert np.all(np.isfinite(a))
+    assert np.array_equal(a, b), (name, sweeps, float(np.abs(a - b).max()))
+    assert sb["operator_sweeps"] == sweeps == sa["operator_sweeps"]
+    # the displacement sums are reduced in a different (still deterministic) order
+    assert sb["last_dx2"] == pytest.approx(sa["last_dx2"], rel=1e-11, abs=1e-300)
+    assert sb["last_dy2"] == pytest.approx(sa["last_dy2"], rel=1e-11, abs=1e-300)
+
+
+# block shapes around the tiling edges: 60-column strips (4 per workgroup = 240), 64-row chunks, the 5 x 5 minimum
+SHAPES = [(5, 5), (5, 64), (6, 61), (7, 62), (61, 63), (63, 121), (66, 122), (67, 181), (130, 241), (131, 242), (129, 243), (200, 483)]
+
+
+@pytest.mark.parametrize("ni,nj", SHAPES)
+def test_fused_pairs_block_shapes(ni, nj):
+    build = lambda: configs.single_block(ni, nj, perturb=0.2)
+    a, _ = _run(build, 4, single=True, omega=0.9)
+    b, _ = _run(build, 4, single=False, omega=0.9)
+    assert np.array_equal(a, b), (ni, nj, float(np.abs(a - b).max()))
+    assert not np.array_equal(a, mesh_flat(build()))   # the sweeps moved the mesh
+
+
+def test_fused_pairs_across_calls_and_small_blocks_fall_back():
+    build = lambda: configs.strip(3, 33, 70, reverse_odd=True)
+    a, _ = _run(build, 9, single=True)
+    b, _ = _run(build, 9, single=False, chunks=[1, 2, 3, 3])   # 1 | pair | pair+1 | pair+1
+    assert np.array_equal(a, b)
+    # a block below 5 x 5 cannot hold the two-sweep window: the handle silently takes single sweeps
+    build = lambda: configs.strip(2, 4, 9)
+    a, _ = _run(build, 6, single=True)
+    b, _ = _run(build, 6, single=False)
+    assert np.array_equal(a, b)
+
+
+def test_fused_pairs_multiblock_large():
+    build = lambda: configs.strip(2, 300, 1000, reverse_odd=True)
+    a, _ = _run(build, 6, single=True)
+    b, _ = _run(build, 6, single=False)
+    assert np.array_equal(a, b)

@@ -10,12 +10,12 @@ from turbomesh_amd.smoothing import smooth, solver
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 20
 mode = sys.argv[3] if len(sys.argv) > 3 else "relax"
-ring = int(sys.argv[4]) if len(sys.argv) > 4 else -1
-if ring >= 0:
-    _capi.lib().tm_tune_ring(ring)
+single = len(sys.argv) > 4 and sys.argv[4] == "single"   # one sweep per kernel pass (K2) instead of pairs (K2x2)
+if os.environ.get('TM_FUSE_ROWS'):
+    _capi.lib().tm_tune_fuse(int(os.environ['TM_FUSE_ROWS']))
 mesh = configs.single_block(n, n)
 if mode == "relax":
-    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax, single_sweep=single)) as sm:
         sm.iterate(steps)
 else:
     with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.bicgstab, max_inner=steps, rtol=1e-30)) as sm:

@@ -59,7 +59,6 @@ del a, b
 
 mesh = configs.single_block(n, n)
 tag = os.environ.get("TM_TUNE_TAG", "default")
-L.tm_tune_ring(8)
 # Krylov apply (48-64 B/node: frozen field + vector in, vector out) through the BiCGStab path
 for rows, unroll, pipe in ():
     _capi.lib().tm_tune_apply(rows, unroll, pipe, 0)

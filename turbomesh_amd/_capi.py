@@ -60,7 +60,7 @@ class tm_control_fn(C.Structure):
 
 class tm_solver_opt(C.Structure):
     _fields_ = [("tag", C.c_int32), ("inner", C.c_int32), ("rtol", C.c_double), ("atol", C.c_double), ("max_inner", C.c_uint64),
-                ("check_every", C.c_uint32), ("_pad", C.c_uint32), ("omega", C.c_double)]
+                ("check_every", C.c_uint32), ("flags", C.c_uint32), ("omega", C.c_double)]
 
 
 class tm_stats(C.Structure):
@@ -152,7 +152,7 @@ def lib():
         L.tm_dev_relax_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_void_p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.c_void_p]
         L.tm_diag_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
-        L.tm_tune_ring.argtypes = [C.c_int]
+        L.tm_tune_fuse.argtypes = [C.c_int]
         L.tm_tune_apply.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib

@@ -100,8 +100,8 @@ int tm_tune_apply(int rows_per_chunk, int unroll, int pipe, int nt) {
     return TM_OK;
 }
 
-int tm_tune_ring(int depth) {
-    tune_ring(depth);
+int tm_tune_fuse(int rows_per_chunk) {
+    tune_fuse_rows(rows_per_chunk);
     return TM_OK;
 }
 // diagnostic: K2 with the same tiling / data movement but reduced arithmetic (mode 4 = copy, 5 = 9-point sum)

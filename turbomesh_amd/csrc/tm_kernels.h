@@ -42,9 +42,26 @@ struct ApplyBlock {
 };
 // number of workgroups k2 launches for a block (also the number of partial rows it writes)
 int apply_block_nwg(int ni, int nj);
-void tune_ring(int depth);   // LDS-DMA ring depth of the field-mode relax kernel (0 = register path)
 void tune_apply(int rows_per_chunk, int unroll, int pipe, int nt);   // <=0 (pipe, nt: <0) keeps the current value
 hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_t stream);
+
+// ---- K2x2: TWO fused Jacobi sweeps of one block in one pass (field mode, Laplace).  `in` = X^k (all rows),
+// `mid` = X^(k+1): its perimeter rows must already hold the perimeter-row kernel's result for X^k; the kernel
+// reads them and WRITES the first-interior ring of X^(k+1) into it (what the next perimeter-row kernel and the
+// halo exchange need); `out` = X^(k+2) interior rows.  Same arithmetic as two K2 launches, bit for bit.
+struct Relax2Block {
+    const double2* in;
+    double2* mid;
+    double2* out;
+    int ni, nj;
+    double omega;
+    double* partials;   // [nwg * MAX_PARTIALS]: sum (X^(k+2) - X^(k+1))^2 over interior rows
+};
+bool relax2_supported(int ni, int nj);
+int relax2_rows_per_chunk(int ni, int nj);   // rows per workgroup chosen for this block on this device (fixed at handle creation)
+int relax2_block_nwg(int ni, int nj, int rows_per_chunk);
+hipError_t launch_relax2_block(const Relax2Block& a, int rows_per_chunk, int dot, hipStream_t stream);
+void tune_fuse_rows(int rows);
 
 // ---- K4/K5 perimeter rows (device SoA, built on the host by tm_plan)
 struct EdgeRowsDev {

@@ -47,6 +47,24 @@ __device__ __forceinline__ double lane_next(double edge, double v) {
 __device__ __forceinline__ double2 lane_prev(double2 edge, double2 v) { return make_double2(lane_prev(edge.x, v.x), lane_prev(edge.y, v.y)); }
 __device__ __forceinline__ double2 lane_next(double2 edge, double2 v) { return make_double2(lane_next(edge.x, v.x), lane_next(edge.y, v.y)); }
 
+// zero-fill variants (bound_ctrl): the wave-edge lane receives 0 and no `old` register has to be prepared
+__device__ __forceinline__ double2 lane_prev0(double2 v) {
+    int4 s = __builtin_bit_cast(int4, v), r;
+    r.x = __builtin_amdgcn_update_dpp(0, s.x, 0x138, 0xf, 0xf, true);
+    r.y = __builtin_amdgcn_update_dpp(0, s.y, 0x138, 0xf, 0xf, true);
+    r.z = __builtin_amdgcn_update_dpp(0, s.z, 0x138, 0xf, 0xf, true);
+    r.w = __builtin_amdgcn_update_dpp(0, s.w, 0x138, 0xf, 0xf, true);
+    return __builtin_bit_cast(double2, r);
+}
+__device__ __forceinline__ double2 lane_next0(double2 v) {
+    int4 s = __builtin_bit_cast(int4, v), r;
+    r.x = __builtin_amdgcn_update_dpp(0, s.x, 0x130, 0xf, 0xf, true);
+    r.y = __builtin_amdgcn_update_dpp(0, s.y, 0x130, 0xf, 0xf, true);
+    r.z = __builtin_amdgcn_update_dpp(0, s.z, 0x130, 0xf, 0xf, true);
+    r.w = __builtin_amdgcn_update_dpp(0, s.w, 0x130, 0xf, 0xf, true);
+    return __builtin_bit_cast(double2, r);
+}
+
 __device__ __forceinline__ double wave_sum(double v) {
 #pragma unroll
     for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
@@ -150,29 +168,29 @@ __device__ __forceinline__ void accumulate(double (&acc)[MAX_PARTIALS], double2 
 // oracle's mirror of this very sequence (oracle/orc_mirror.cpp): every fma below is explicit,
 // everything else is built with -ffp-contract=off.
 // ------------------------------------------------------------------------------------------
-template <int MODE, bool HAS_PQ>
-__device__ __forceinline__ double2 winslow_row(double2 m_l, double2 m_c, double2 m_r, double2 c_l, double2 c_c, double2 c_r, double2 p_l,
-                                               double2 p_c, double2 p_r, double2 xm, double2 xp, double2 xl, double2 xr, double P, double Q,
-                                               double omega, double2& delta) {
-    const double dxi_x = xp.x - xm.x, dxi_y = xp.y - xm.y;
-    const double det_x = xr.x - xl.x, det_y = xr.y - xl.y;
-    const double G11 = fma(dxi_x, dxi_x, dxi_y * dxi_y);
-    const double G22 = fma(det_x, det_x, det_y * det_y);
-    const double G12 = fma(dxi_x, det_x, dxi_y * det_y);
+// A row of the vector enters as (c, e, h): the value and, from the two lane shifts done once when the row is loaded,
+// e = w(i,j+1) - w(i,j-1) and h = w(i,j+1) + w(i,j-1).  The cross term is k = e(i+1) - e(i-1).
+// dxi = xk(i+1,j) - xk(i-1,j), det = xk(i,j+1) - xk(i,j-1): the frozen field's differences (field mode: p_c - m_c and e_c).
+template <int MODE, bool HAS_PQ, bool UNIT_OMEGA = false>
+__device__ __forceinline__ double2 winslow_row(double2 m_c, double2 e_m, double2 c_c, double2 e_c, double2 h_c, double2 p_c, double2 e_p, double2 dxi,
+                                               double2 det, double P, double Q, double omega, double2& delta) {
+    const double G11 = fma(dxi.x, dxi.x, dxi.y * dxi.y);
+    const double G22 = fma(det.x, det.x, det.y * det.y);
+    const double G12 = fma(dxi.x, det.x, dxi.y * det.y);
     const double D = G11 + G22;
     const double m2D = -2.0 * D;      // 4 a_ii
     const double mhG12 = -0.5 * G12;
     double ax = p_c.x + m_c.x, ay = p_c.y + m_c.y;
-    double bx = c_r.x + c_l.x, by = c_r.y + c_l.y;
+    double bx = h_c.x, by = h_c.y;
     if (HAS_PQ) {
         const double hP = 0.5 * P, hQ = 0.5 * Q;
         ax = fma(hP, p_c.x - m_c.x, ax);
         ay = fma(hP, p_c.y - m_c.y, ay);
-        bx = fma(hQ, c_r.x - c_l.x, bx);
-        by = fma(hQ, c_r.y - c_l.y, by);
+        bx = fma(hQ, e_c.x, bx);
+        by = fma(hQ, e_c.y, by);
     }
-    const double kx = (p_r.x + m_l.x) - (p_l.x + m_r.x);
-    const double ky = (p_r.y + m_l.y) - (p_l.y + m_r.y);
+    const double kx = e_p.x - e_m.x;
+    const double ky = e_p.y - e_m.y;
     double sx = G22 * ax, sy = G22 * ay;
     sx = fma(G11, bx, sx);
     sy = fma(G11, by, sy);
@@ -185,9 +203,13 @@ __device__ __forceinline__ double2 winslow_row(double2 m_l, double2 m_c, double2
     const double tx = sx * rinv, ty = sy * rinv;          // (D^-1 A w)_row
     if (MODE == MODE_SCALED) return make_double2(tx, ty);
     if (MODE == MODE_RESID) return make_double2(-tx, -ty);   // b = 0 on interior rows
-    delta = make_double2(omega * (-tx), omega * (-ty));       // MODE_RELAX: the displacement of this sweep
+    // MODE_RELAX: the displacement of this sweep (omega == 1: the product is exact, so it is skipped)
+    delta = UNIT_OMEGA ? make_double2(-tx, -ty) : make_double2(omega * (-tx), omega * (-ty));
     return make_double2(c_c.x + delta.x, c_c.y + delta.y);
 }
+
+__device__ __forceinline__ double2 sub2(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
+__device__ __forceinline__ double2 add2(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 
 // ------------------------------------------------------------------------------------------
 // K2  winslow_apply: interior rows of one block (replaces smooth.zig:923-992 fill +
@@ -233,23 +255,23 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
             h = make_double2(0.0, 0.0);   // NOT `h = c`: that copy would force a vmcnt(0) wait right behind every row load
             if (edge_lane) h = rp[hcol];
         };
-        // 3-row window of the vector, rotating by index: slot (r % 3) holds row i0-1+r; l/r = columns j-1/j+1
-        double2 Wc[3], Wl[3], Wr[3];
-        double2 Xc[3], Xl = make_double2(0.0, 0.0), Xr = make_double2(0.0, 0.0);   // frozen coordinates when they are a different array
+        // 3-row window of the vector, rotating by index: slot (r % 3) holds row i0-1+r as (value, e = right - left, h = right + left)
+        double2 Wc[3], We[3], Wh[3];
+        double2 Xc[3], Xdet = make_double2(0.0, 0.0);   // frozen coordinates when they are a different array; Xdet of the centre row
         {
             double2 h0, h1;
             load_row(a.in, i0 - 1, Wc[0], h0);
             load_row(a.in, i0, Wc[1], h1);
-            Wl[0] = lane_prev(h0, Wc[0]); Wr[0] = lane_next(h0, Wc[0]);
-            Wl[1] = lane_prev(h1, Wc[1]); Wr[1] = lane_next(h1, Wc[1]);
-            Wc[2] = Wl[2] = Wr[2] = make_double2(0.0, 0.0);
+            const double2 l0 = lane_prev(h0, Wc[0]), r0 = lane_next(h0, Wc[0]), l1 = lane_prev(h1, Wc[1]), r1 = lane_next(h1, Wc[1]);
+            We[0] = sub2(r0, l0); Wh[0] = add2(r0, l0);
+            We[1] = sub2(r1, l1); Wh[1] = add2(r1, l1);
+            Wc[2] = We[2] = Wh[2] = make_double2(0.0, 0.0);
             Xc[0] = Xc[1] = Xc[2] = make_double2(0.0, 0.0);
             if (!FIELD) {
                 double2 t_h;
                 load_row(a.xk, i0 - 1, Xc[0], t_h);
                 load_row(a.xk, i0, Xc[1], t_h);
-                Xl = lane_prev(t_h, Xc[1]);
-                Xr = lane_next(t_h, Xc[1]);
+                Xdet = sub2(lane_next(t_h, Xc[1]), lane_prev(t_h, Xc[1]));
             }
         }
 
@@ -262,7 +284,7 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
                 const int prow = min(ib + u + 1, ni - 1);
                 if (MODE == MODE_DIAG_NOLOAD || MODE == MODE_DIAG_MATH) {
                     g.pc[u] = Wc[1];
-                    g.ph[u] = Wl[1];
+                    g.ph[u] = Wh[1];
                 } else
                     load_row(a.in, prow, g.pc[u], g.ph[u]);
                 if (!FIELD) load_row(a.xk, prow, g.xpc[u], g.xph[u]);
@@ -279,8 +301,11 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
                 const int M = u % 3, C = (u + 1) % 3, P3 = (u + 2) % 3;   // window slots of rows i-1, i, i+1
                 const int row = ib + u;
                 Wc[P3] = g.pc[u];
-                Wl[P3] = lane_prev(g.ph[u], g.pc[u]);
-                Wr[P3] = lane_next(g.ph[u], g.pc[u]);
+                {
+                    const double2 l = lane_prev(g.ph[u], g.pc[u]), r = lane_next(g.ph[u], g.pc[u]);
+                    We[P3] = sub2(r, l);
+                    Wh[P3] = add2(r, l);
+                }
                 if (!FIELD) Xc[P3] = g.xpc[u];
 
                 const double P = HAS_PQ ? g.pqv[u].x : 0.0, Q = HAS_PQ ? g.pqv[u].y : 0.0;
@@ -288,14 +313,14 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
                 if (MODE == MODE_DIAG_COPY) {
                     o = Wc[C];
                 } else if (MODE == MODE_DIAG_SUM9) {
-                    o.x = Wl[M].x + Wc[M].x + Wr[M].x + Wl[C].x + Wc[C].x + Wr[C].x + Wl[P3].x + Wc[P3].x + Wr[P3].x;
-                    o.y = Wl[M].y + Wc[M].y + Wr[M].y + Wl[C].y + Wc[C].y + Wr[C].y + Wl[P3].y + Wc[P3].y + Wr[P3].y;
+                    o.x = Wh[M].x + Wc[M].x + Wh[C].x + Wc[C].x + Wh[P3].x + Wc[P3].x;
+                    o.y = Wh[M].y + Wc[M].y + Wh[C].y + Wc[C].y + Wh[P3].y + Wc[P3].y;
                 } else if (MODE == MODE_DIAG_NOSTORE || MODE == MODE_DIAG_NOLOAD || MODE == MODE_DIAG_MATH) {
-                    o = winslow_row<MODE_RELAX, HAS_PQ>(Wl[M], Wc[M], Wr[M], Wl[C], Wc[C], Wr[C], Wl[P3], Wc[P3], Wr[P3], Wc[M], Wc[P3], Wl[C], Wr[C], P, Q, a.omega, delta);
+                    o = winslow_row<MODE_RELAX, HAS_PQ>(Wc[M], We[M], Wc[C], We[C], Wh[C], Wc[P3], We[P3], sub2(Wc[P3], Wc[M]), We[C], P, Q, a.omega, delta);
                 } else if (FIELD) {
-                    o = winslow_row<MODE, HAS_PQ>(Wl[M], Wc[M], Wr[M], Wl[C], Wc[C], Wr[C], Wl[P3], Wc[P3], Wr[P3], Wc[M], Wc[P3], Wl[C], Wr[C], P, Q, a.omega, delta);
+                    o = winslow_row<MODE, HAS_PQ>(Wc[M], We[M], Wc[C], We[C], Wh[C], Wc[P3], We[P3], sub2(Wc[P3], Wc[M]), We[C], P, Q, a.omega, delta);
                 } else {
-                    o = winslow_row<MODE, HAS_PQ>(Wl[M], Wc[M], Wr[M], Wl[C], Wc[C], Wr[C], Wl[P3], Wc[P3], Wr[P3], Xc[M], Xc[P3], Xl, Xr, P, Q, a.omega, delta);
+                    o = winslow_row<MODE, HAS_PQ>(Wc[M], We[M], Wc[C], We[C], Wh[C], Wc[P3], We[P3], sub2(Xc[P3], Xc[M]), Xdet, P, Q, a.omega, delta);
                 }
                 if (MODE == MODE_DIAG_NOSTORE || MODE == MODE_DIAG_MATH) {
                     acc[0] += o.x;
@@ -312,10 +337,7 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
                     }
                     accumulate<DOT>(acc, Wc[C], o, (DOT == DOT_AUX) ? g.auxv[u] : ((DOT == DOT_DELTA) ? delta : o));
                 }
-                if (!FIELD) {   // l/r of the frozen field for the next row (= row i+1)
-                    Xl = lane_prev(g.xph[u], g.xpc[u]);
-                    Xr = lane_next(g.xph[u], g.xpc[u]);
-                }
+                if (!FIELD) Xdet = sub2(lane_next(g.xph[u], g.xpc[u]), lane_prev(g.xph[u], g.xpc[u]));   // of the next centre row (= row i+1)
             }
         };
 
@@ -337,43 +359,191 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
     if (DOT != DOT_NONE) block_partials<256>(acc, a.partials + static_cast<size_t>(bid) * MAX_PARTIALS);
 }
 
+
 // ------------------------------------------------------------------------------------------
-// K2, LDS-DMA ring variant (field mode, Laplace): the same marching tile, but every wave streams
-// its rows HBM -> LDS with `global_load_lds_dwordx4` (no VGPR destination) into a private ring of
-// R row slots, so R-1 rows (about R KiB per wave, >100 KB per CU) are in flight while the wave
-// computes -- the register path can only keep what its VGPR budget holds.  A slot holds the 66
-// columns j0-1 .. j0+64, so the j-1 / j+1 neighbours are plain ds_read_b128 at +-16 B: no lane
-// shifts, no halo registers.  hipcc does not count LDS-DMA, so completion is tracked by hand:
-// VMEM operations retire in issue order and the only other VMEM operation in the loop is the one
-// store per row, hence "row q has landed" == `s_waitcnt vmcnt(<ops issued after row q's DMAs>)`.
+// K2x2: two fused Jacobi sweeps per pass (temporal blocking in registers).
+//   a  = X^k      rows i, i+1, i+2  (3-row window, one coalesced load per row)
+//   s1 = X^(k+1)  rows i-1, i, i+1  (computed from `a`; perimeter values come from `mid`)
+//   s2 = X^(k+2)  row i             (computed from s1, stored)
+// A wave loads the 64 columns c0-2 .. c0+61 and owns the 60 output columns c0 .. c0+59
+// (c0 = 60*strip: every stored segment is a whole number of 64 B sectors); s1 is valid on lanes
+// 1..62, s2 on lanes 2..61, so the j-halo comes with the row load itself and no edge-lane loads
+// are needed.  Row chunks overlap by two rows on each side.  HBM traffic per PAIR of sweeps is
+// one read (x 64/60 x (RI+4)/RI, the overlap mostly hits L2) and one write of the field.
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void glds16(const void* gsrc, unsigned lds_dst) {
-    unsigned keep;
-    // lgkmcnt(0): the slot's previous occupant has been read out before the DMA may overwrite it
-    asm volatile(
-        "s_waitcnt lgkmcnt(0)\n\t"
-        "s_mov_b32 %0, m0\n\t"
-        "s_mov_b32 m0, %2\n\t"
-        "s_nop 0\n\t"
-        "global_load_lds_dwordx4 %1, off\n\t"
-        "s_mov_b32 m0, %0"
-        : "=&s"(keep)
-        : "v"(gsrc), "s"(lds_dst)
-        : "memory");
+struct Relax2Tile {
+    int c0, c, i0, i1;   // first owned column, this lane's column, owned rows [i0, i1)
+    bool out_lane;       // lanes 2..61 on interior columns: store s2 (and the ring of s1)
+};
+
+constexpr unsigned OOB_VOFFSET = 0x80000000u;   // beyond num_records of every buffer resource below: the hardware drops the lane's store
+
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+// A row in window form: value, e = right - left, h = right + left (zero-fill shifts: lanes 0 / 63 hold garbage there)
+struct Row3 {
+    double2 c, e, h;
+};
+__device__ __forceinline__ Row3 make_row(double2 c) {
+    const double2 l = lane_prev0(c), r = lane_next0(c);
+    Row3 w;
+    w.c = c;
+    w.e = sub2(r, l);
+    w.h = add2(r, l);
+    return w;
 }
-template <int N>
-__device__ __forceinline__ void wait_vmcnt() {
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+// one Jacobi sweep at the centre row of (m, c, p), field mode
+template <bool W1>
+__device__ __forceinline__ double2 relax_row(const Row3& m, const Row3& c, const Row3& p, double omega, double2& delta) {
+    return winslow_row<MODE_RELAX, false, W1>(m.c, m.e, c.c, c.e, c.h, p.c, p.e, sub2(p.c, m.c), c.e, 0.0, 0.0, omega, delta);
 }
 
-static int g_ring = 0;   // ring depth R (0 = use the register path, the default: same speed, simpler)
+// One wave, one 60-column strip, rows [i0, i1): the strips along the block edge (and short last chunks).  Perimeter values of
+// X^(k+1) come from `mid`, the first-interior ring of X^(k+1) goes to it; every row / column index is clamped.  Written like the
+// inside path below -- straight-line steps, loads one group ahead, every predicate folded into a select or into the offset of
+// a buffer store -- because a workgroup on the edge that waits out the full memory latency at every step would still be running
+// long after the rest of the launch has drained.
+template <int DOT, int U, bool NT, bool W1>
+__device__ __forceinline__ void relax2_strip_edge(const Relax2Block& a, const Relax2Tile& t, double (&acc)[MAX_PARTIALS]) {
+    const int ni = a.ni, nj = a.nj;
+    const int cc = min(max(t.c, 0), nj - 1);
+    const double2* in_col = a.in + cc;
+    const double2* mid_col = a.mid + cc;
+    const double2 zero = make_double2(0.0, 0.0);
+    auto load_in = [&](int row) { return in_col[static_cast<size_t>(min(max(row, 0), ni - 1)) * nj]; };
+    auto load_mid = [&](int row) { return mid_col[static_cast<size_t>(min(max(row, 0), ni - 1)) * nj]; };
+    const bool perim_col = (t.c == 0) || (t.c == nj - 1);
+    const bool ring_col = (t.c == 1) || (t.c == nj - 2);
+    const int nrows = t.i1 - t.i0;
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + static_cast<size_t>(t.i0) * nj, 0, nrows * nj * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mid_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.mid + static_cast<size_t>(t.i0) * nj, 0, nrows * nj * 16, 0x00020000);
+    const unsigned lane_off = static_cast<unsigned>(cc) * 16u;
 
-template <int MODE, int DOT, int R, bool NT>
-__global__ __launch_bounds__(256) void k_apply_ring(ApplyBlock a, int RI, int nSG, int nRC) {
-    constexpr int SLOT = 66 * 16;   // bytes per row slot
-    __shared__ __attribute__((aligned(16))) char lds[4 * R * SLOT];
+    Row3 A[3], S[3];
+    double2 pa[U], na[U], pm;
+    // step s handles row i = i0 - 2 + s: takes a[i+2], forms s1[i+1], then s2[i]; a[i], a[i+1] are preloaded.
+    // pa / na: rows a[i+2] of this group's / the next group's steps; pm: X^(k+1) perimeter value of the next step's row
+    {
+        const double2 a0 = load_in(t.i0 - 2), a1 = load_in(t.i0 - 1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) pa[u] = load_in(t.i0 + u);
+        pm = load_mid(t.i0 - 1);
+        A[0] = make_row(a0);
+        A[1] = make_row(a1);
+        A[2].c = A[2].e = A[2].h = zero;
+        S[0] = S[1] = S[2] = A[2];
+    }
+    const int nsteps = nrows + 2;
+    auto group = [&](const int tb) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) na[u] = load_in(t.i0 + tb + U + u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int A0 = u % 3, A1 = (u + 1) % 3, A2 = (u + 2) % 3;   // slots of a[i], a[i+1], a[i+2] and of s1[i-1], s1[i], s1[i+1]
+            const int i = t.i0 - 2 + tb + u;
+            const int q = i + 1;   // the s1 row formed in this step
+            A[A2] = make_row(pa[u]);
+            const double2 pm_now = pm;
+            pm = load_mid(q + 1);   // one step ahead
+            // ---- s1[q]: first sweep at row q; on the perimeter the perimeter-row kernel's value
+            double2 d1 = zero;
+            double2 s1 = relax_row<W1>(A[A0], A[A1], A[A2], a.omega, d1);
+            const bool perim_row = (q <= 0) || (q >= ni - 1);
+            if (perim_row || perim_col) s1 = pm_now;   // a select: both values are in registers
+            // this wave's chunk owns row q of s1: leave the first-interior ring of X^(k+1) (all other lanes: offset out of range)
+            const bool ring = t.out_lane && !perim_row && (q >= t.i0) && (q < t.i1) && ((q == 1) || (q == ni - 2) || ring_col);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, s1), mid_rsrc,
+                                                   static_cast<int>(ring ? lane_off + static_cast<unsigned>((q - t.i0) * nj * 16) : OOB_VOFFSET), 0, 0);
+            S[A2] = make_row(s1);
+            // ---- s2[i]: second sweep at row i (not in the two warm-up steps, not past a short chunk)
+            double2 d2 = zero;
+            const double2 o = relax_row<W1>(S[A0], S[A1], S[A2], a.omega, d2);
+            const bool live = t.out_lane && (i >= t.i0) && (i < t.i1);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, o), out_rsrc,
+                                                   static_cast<int>(live ? lane_off + static_cast<unsigned>((i - t.i0) * nj * 16) : OOB_VOFFSET), 0, NT ? 2 : 0);
+            if (DOT == DOT_DELTA) {
+                if (!live) d2 = zero;
+                accumulate<DOT_DELTA>(acc, S[A1].c, o, d2);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) pa[u] = na[u];
+    };
+    group(0);   // peeled: see relax2_strip_inside
+    for (int tb = U; tb < nsteps; tb += U) group(tb);
+}
+
+// The same strip strictly inside the block (no perimeter row / column, no ring, RI = i1 - i0 a multiple of U): the steady state.
+// The loop body is ONE basic block -- gfx9 counts loads and stores in a single in-order counter (vmcnt) and the compiler merges
+// the counter state wherever control flow joins, so any branch around a load or store makes every wait for a prefetched row
+// also wait for the stores issued since.  Hence: lane predication of the store by a buffer store whose masked lanes carry an
+// out-of-range offset (dropped by the hardware), no row predicates, the next group's rows requested before this group's
+// arithmetic, and the first group peeled so that both loop entries see the same queue of outstanding operations.
+template <int DOT, int U, bool NT, bool W1>
+__device__ __forceinline__ void relax2_strip_inside(const Relax2Block& a, const Relax2Tile& t, double (&acc)[MAX_PARTIALS]) {
+    const int nj = a.nj;
+    const double2* in_col = a.in + t.c;
+    const int last_row = t.i1 + 1;   // last row of `in` this strip needs; prefetches past it re-read it
+    auto load_in = [&](int row) { return in_col[static_cast<size_t>(min(row, last_row)) * nj]; };
+    const __amdgpu_buffer_rsrc_t out_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc(a.out + static_cast<size_t>(t.i0) * nj, 0, (t.i1 - t.i0) * nj * 16, 0x00020000);
+    const unsigned voff = t.out_lane ? static_cast<unsigned>(t.c) * 16u : OOB_VOFFSET;
+
+    Row3 A[3], S[3];
+    double2 pc[U], pn[U];   // rows a[i+2] of this group's steps / of the next group's (requested one group ahead)
+    {   // warm-up: s1[i0-1], s1[i0] from a[i0-2 .. i0+1]
+        const double2 am2 = load_in(t.i0 - 2), am1 = load_in(t.i0 - 1), a0 = load_in(t.i0), a1 = load_in(t.i0 + 1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) pc[u] = load_in(t.i0 + 2 + u);
+        const Row3 rm2 = make_row(am2), rm1 = make_row(am1);
+        A[0] = make_row(a0);
+        A[1] = make_row(a1);
+        double2 d = make_double2(0.0, 0.0);
+        S[0] = make_row(relax_row<W1>(rm2, rm1, A[0], a.omega, d));
+        S[1] = make_row(relax_row<W1>(rm1, A[0], A[1], a.omega, d));
+        A[2].c = A[2].e = A[2].h = make_double2(0.0, 0.0);
+        S[2] = A[2];
+    }
+    auto group = [&](const int tb) {   // rows i0+tb .. i0+tb+U-1
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+#if defined(TM_R2_DIAG) && (TM_R2_DIAG & 1)
+            pn[u] = make_double2(pc[u].x * 1.0000001, pc[u].y);   // diagnostic build: no loads in the steady state
+#else
+            pn[u] = load_in(t.i0 + tb + U + 2 + u);
+#endif
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int A0 = u % 3, A1 = (u + 1) % 3, A2 = (u + 2) % 3;   // slots of a[i], a[i+1], a[i+2] and of s1[i-1], s1[i], s1[i+1]
+            A[A2] = make_row(pc[u]);
+            double2 d1 = make_double2(0.0, 0.0), d2 = make_double2(0.0, 0.0);
+            S[A2] = make_row(relax_row<W1>(A[A0], A[A1], A[A2], a.omega, d1));
+            const double2 o = relax_row<W1>(S[A0], S[A1], S[A2], a.omega, d2);
+            // the row offset travels in the VGPR offset: with an SGPR soffset the 128-bit store data was observed to be picked
+            // up late (lanes 12..15 of each 16 saw a later VALU result) -- measured on gfx950, tools/dbg_fused.py
+#if defined(TM_R2_DIAG) && (TM_R2_DIAG & 2)
+            acc[2] += o.x + o.y;   // diagnostic build: no stores
+#else
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, o), out_rsrc, static_cast<int>(voff + static_cast<unsigned>((tb + u) * nj * 16)), 0,
+                                                   NT ? 2 : 0);
+#endif
+            if (DOT == DOT_DELTA) {
+                if (!t.out_lane) d2 = make_double2(0.0, 0.0);   // masked lanes hold garbage (possibly non-finite): select, never multiply
+                accumulate<DOT_DELTA>(acc, S[A1].c, o, d2);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) pc[u] = pn[u];
+    };
+    group(0);
+    for (int tb = U; tb < t.i1 - t.i0; tb += U) group(tb);
+}
+
+template <int DOT, int U, bool NT, bool W1>
+__global__ __launch_bounds__(256) void k_relax2(Relax2Block a, int RI, int nSG, int nRC) {
+    static_assert(U % 3 == 0, "windows rotate by renaming");
     const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int wave = threadIdx.x >> 6;
     const int total = nSG * nRC;
     const int bid = blockIdx.x;
     const int q8 = total >> 3, rem = total & 7, xcd = bid & 7, k8 = bid >> 3;
@@ -382,86 +552,72 @@ __global__ __launch_bounds__(256) void k_apply_ring(ApplyBlock a, int RI, int nS
     const int sg = logical - rc * nSG;
 
     const int ni = a.ni, nj = a.nj;
-    const int j0 = (sg * 4 + wave) * 64;
-    const int j = j0 + lane;
-    const bool valid_col = (j >= 1) && (j <= nj - 2);
-    const int i0 = 1 + rc * RI;
-    const int i1 = min(i0 + RI, ni - 1);   // output rows [i0, i1)
+    Relax2Tile t;
+    t.c0 = (sg * 4 + wave) * 60;
+    t.c = t.c0 - 2 + lane;
+    t.out_lane = (lane >= 2) && (lane <= 61) && (t.c >= 1) && (t.c <= nj - 2);
+    t.i0 = 1 + rc * RI;
+    t.i1 = min(t.i0 + RI, ni - 1);
 
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
-
-    // a wave takes part only if it owns at least one output column (keeps the VMEM op count per row exact)
-    if (max(j0, 1) <= min(j0 + 63, nj - 2) && i0 < i1) {   // wave-uniform
-        const unsigned wbase = static_cast<unsigned>(reinterpret_cast<uintptr_t>(lds)) + static_cast<unsigned>(wave * R * SLOT);
-        const int c_main = min(max(j0 - 1 + lane, 0), nj - 1);    // slot element e <-> column j0-1+e
-        const int c_tail = min(j0 + 63 + lane, nj - 1);            // lanes 0,1: elements 64,65
-        auto dma_row = [&](int qrow, int slot) {
-            const double2* rp = a.in + static_cast<size_t>(min(qrow, ni - 1)) * nj;
-            const unsigned dst = wbase + static_cast<unsigned>(slot * SLOT);
-            glds16(rp + c_main, dst);
-            if (lane < 2) glds16(rp + c_tail, dst + 1024u);
-        };
-        int q = i0 - 1;
-#pragma unroll
-        for (int k = 0; k < R; ++k) dma_row(q + k, k);   // prologue: R rows in flight
-
-        double2 m_l, m_c, m_r, c_l, c_c, c_r;
-        m_l = m_c = m_r = c_l = c_c = c_r = make_double2(0.0, 0.0);
-        int slot = 0;
-        auto step = [&](auto nwait) {
-            constexpr int N = decltype(nwait)::value;
-            wait_vmcnt<N>();   // row q has landed in its slot
-            const double2* srow = reinterpret_cast<const double2*>(lds + wave * R * SLOT + slot * SLOT);
-            const double2 p_l = srow[lane], p_c = srow[lane + 1], p_r = srow[lane + 2];
-            dma_row(q + R, slot);   // refill the slot (glds16 waits lgkmcnt(0) first)
-            if (q >= i0 + 1) {
-                const int row = q - 1;
-                double2 delta = make_double2(0.0, 0.0);
-                const double2 o = winslow_row<MODE, false>(m_l, m_c, m_r, c_l, c_c, c_r, p_l, p_c, p_r, m_c, p_c, c_l, c_r, 0.0, 0.0, a.omega, delta);
-                if (valid_col) {
-                    double2* dst = a.out + static_cast<size_t>(row) * nj + j;
-                    if (NT) {
-                        d2v ov;
-                        ov.x = o.x;
-                        ov.y = o.y;
-                        __builtin_nontemporal_store(ov, reinterpret_cast<d2v*>(dst));
-                    } else {
-                        *dst = o;
-                    }
-                    accumulate<DOT>(acc, c_c, o, (DOT == DOT_DELTA) ? delta : o);
-                }
-            }
-            m_l = c_l; m_c = c_c; m_r = c_r;
-            c_l = p_l; c_c = p_c; c_r = p_r;
-            slot = (slot + 1 == R) ? 0 : slot + 1;
-            q += 1;
-        };
-        // ops issued after row q's two DMAs: the DMAs of rows q+1..q+R-1, plus one store per step since then.
-        // Warm-up (fewer stores issued so far): wait with the store-free count (conservative, always safe).
-        constexpr int N_WARM = 2 * (R - 1);
-        constexpr int N_STEADY = 2 * (R - 1) + R;
-        const int q_steady = i0 + R + 1;
-        while (q <= i1 && q < q_steady) step(std::integral_constant<int, N_WARM>{});
-        while (q <= i1) step(std::integral_constant<int, N_STEADY>{});
-        wait_vmcnt<0>();   // no LDS-DMA may outlive the wave
+    if (t.c0 <= nj - 2 && t.i0 < t.i1) {   // wave-uniform
+        // strictly inside: columns c0-2 .. c0+61 within [2, nj-3], rows i0-2 .. i1+1 within [2, ni-3] -> no perimeter, no ring
+        const bool inside = (t.c0 - 2 >= 2) && (t.c0 + 61 <= nj - 3) && (t.i0 - 2 >= 2) && (t.i1 + 1 <= ni - 3) && ((t.i1 - t.i0) % U == 0);
+        if (inside) relax2_strip_inside<DOT, U, NT, W1>(a, t, acc);
+        else relax2_strip_edge<DOT, U, NT, W1>(a, t, acc);
     }
     if (DOT != DOT_NONE) block_partials<256>(acc, a.partials + static_cast<size_t>(bid) * MAX_PARTIALS);
 }
 
-template <int MODE, int DOT>
-static hipError_t launch_apply_ring(const ApplyBlock& a, int RI, int nSG, int nRC, hipStream_t st) {
-    const dim3 grid(nSG * nRC), block(256);
-#define TM_RING(R_) do { if (g_nt) hipLaunchKernelGGL((k_apply_ring<MODE, DOT, R_, true>), grid, block, 0, st, a, RI, nSG, nRC); \
-                         else hipLaunchKernelGGL((k_apply_ring<MODE, DOT, R_, false>), grid, block, 0, st, a, RI, nSG, nRC); } while (0)
-    switch (g_ring) {
-        case 4: TM_RING(4); break;
-        case 6: TM_RING(6); break;
-        case 12: TM_RING(12); break;
-        default: TM_RING(8); break;
+static int g_fuse_rows = 0;   // 0 = choose per block (relax2_rows_per_chunk); > 0 = forced (tm_tune_fuse)
+constexpr int R2_U = 3;      // rows per load group of k_relax2
+
+// Rows per chunk of K2x2.  A workgroup (4 strips x RI rows) runs RI+2 steps and the CU holds 4 of them (104 VGPRs), so the
+// launch proceeds in rounds of 4 x #CU workgroups: pick the RI (a multiple of the load group) that minimises rounds x steps.
+int relax2_rows_per_chunk(int ni, int nj) {
+    const int interior = ni - 2;
+    if (g_fuse_rows > 0) return std::max(1, std::min(g_fuse_rows, interior));
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slots = 4 * cus;
     }
-#undef TM_RING
+    const int nstrips = (nj - 1 + 59) / 60, nSG = (nstrips + 3) / 4;
+    long best_cost = -1;
+    int best = R2_U;
+    for (int RI = 4 * R2_U; RI <= 64 * R2_U; RI += R2_U) {
+        const long nRC = (interior + RI - 1) / RI;
+        const long rounds = (nSG * nRC + slots - 1) / slots;
+        const long cost = rounds * (RI + 2 + 4);   // + prologue / epilogue of a workgroup, in steps
+        if (best_cost < 0 || cost <= best_cost) {
+            best_cost = cost;
+            best = RI;
+        }
+        if (RI >= interior) break;
+    }
+    return best;
+}
+bool relax2_supported(int ni, int nj) { return ni >= 5 && nj >= 5 && nj <= (1 << 20); }   // buffer-store offsets: rows_per_chunk * nj * 16 < 2^31
+int relax2_block_nwg(int ni, int nj, int RI) {
+    const int nstrips = (nj - 1 + 59) / 60;
+    return ((nstrips + 3) / 4) * ((ni - 2 + RI - 1) / RI);
+}
+hipError_t launch_relax2_block(const Relax2Block& a, int RI, int dot, hipStream_t st) {
+    const int nstrips = (a.nj - 1 + 59) / 60;
+    const int nSG = (nstrips + 3) / 4, nRC = (a.ni - 2 + RI - 1) / RI;
+    const dim3 grid(nSG * nRC), block(256);
+    const bool w1 = a.omega == 1.0;
+    if (dot == DOT_DELTA) {
+        if (w1) hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, true>), grid, block, 0, st, a, RI, nSG, nRC);
+        else hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, false>), grid, block, 0, st, a, RI, nSG, nRC);
+    } else {
+        if (w1) hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, true, true>), grid, block, 0, st, a, RI, nSG, nRC);
+        else hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, true, false>), grid, block, 0, st, a, RI, nSG, nRC);
+    }
     return hipGetLastError();
 }
+void tune_fuse_rows(int rows) { g_fuse_rows = rows > 0 ? rows : 0; }
 
 static inline int rows_per_chunk(int ni) {
     const int interior = ni - 2;
@@ -511,10 +667,6 @@ hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_
     if (mode == MODE_SCALED && dot == DOT_IN) return launch_apply_md<MODE_SCALED, DOT_IN>(a, RI, nSG, nRC, st);
     if (mode == MODE_RESID && dot == DOT_OUT2) return launch_apply_md<MODE_RESID, DOT_OUT2>(a, RI, nSG, nRC, st);
     if (mode == MODE_RESID && dot == DOT_NONE) return launch_apply_md<MODE_RESID, DOT_NONE>(a, RI, nSG, nRC, st);
-    if (mode == MODE_RELAX && g_ring > 0 && a.in == a.xk && a.pq == nullptr) {   // field mode, Laplace: LDS-DMA ring
-        if (dot == DOT_DELTA) return launch_apply_ring<MODE_RELAX, DOT_DELTA>(a, RI, nSG, nRC, st);
-        if (dot == DOT_NONE) return launch_apply_ring<MODE_RELAX, DOT_NONE>(a, RI, nSG, nRC, st);
-    }
     if (mode == MODE_RELAX && dot == DOT_DELTA) return launch_apply_md<MODE_RELAX, DOT_DELTA>(a, RI, nSG, nRC, st);
     if (mode == MODE_RELAX && dot == DOT_NONE) return launch_apply_md<MODE_RELAX, DOT_NONE>(a, RI, nSG, nRC, st);
     if (mode == MODE_DIAG_COPY) return launch_apply_md<MODE_DIAG_COPY, DOT_NONE>(a, RI, nSG, nRC, st);
@@ -525,7 +677,6 @@ hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_
     return hipErrorInvalidValue;
 }
 
-void tune_ring(int depth) { g_ring = depth; }
 void tune_apply(int rows, int unroll, int pipe, int nt) {
     if (rows > 0) g_rows_per_chunk = rows;
     if (unroll > 0) g_unroll = unroll;

@@ -178,6 +178,10 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         t = vec();
     }
     if (white) PQ = vec();
+    // two sweeps per pass (K2x2): Laplace control function only (White updates P,Q between sweeps), every owned block >= 5 x 5
+    fuse_pairs = opt.inner == TM_INNER_RELAX && !white && !(opt.flags & TM_OPT_SINGLE_SWEEP);
+    for (int64_t b : lp.owned_blocks) fuse_pairs = fuse_pairs && relax2_supported(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
+    if (fuse_pairs) M = vec();
 
     // ---- perimeter rows -> device SoA with rank-local ids
     const size_t nr = lp.rows.size();
@@ -239,8 +243,21 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     poff_edge = off;
     off += edge_rows_nwg(edge.nrows);
     nwg_apply = off;
+    if (fuse_pairs) {
+        poff2.clear();
+        rows2.clear();
+        int off2 = 0;
+        for (int64_t b : lp.owned_blocks) {
+            const int bi = static_cast<int>(topo.ni[b]), bj = static_cast<int>(topo.nj[b]);
+            poff2.push_back(off2);
+            rows2.push_back(relax2_rows_per_chunk(bi, bj));
+            off2 += relax2_block_nwg(bi, bj, rows2.back());
+        }
+        poff2_edge = off2;
+        nwg_apply2 = off2 + edge_rows_nwg(edge.nrows);
+    }
     nwg_vec = vec_nwg(n_owned);
-    partials = arena.alloc_n<double>(static_cast<uint64_t>(std::max(nwg_apply, nwg_vec)) * MAX_PARTIALS);
+    partials = arena.alloc_n<double>(static_cast<uint64_t>(std::max(std::max(nwg_apply, nwg_apply2), nwg_vec)) * MAX_PARTIALS);
     red = arena.alloc_n<double>(MAX_PARTIALS);
     S = arena.alloc_n<KrylovScalars>(1);
 
@@ -322,6 +339,25 @@ void Smoother::reduce(int nwg) {
     }
 }
 
+// runs `launch`; with profiling on, bracketed by a hipEvent pair on the handle's stream
+void Smoother::profiled(const std::function<void()>& launch) {
+    if (!profile) {
+        launch();
+        return;
+    }
+    if (ev_used == ev_start.size()) {
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        ev_start.push_back(e0);
+        ev_stop.push_back(e1);
+    }
+    HIPCHK(hipEventRecord(ev_start[ev_used], stream));
+    launch();
+    HIPCHK(hipEventRecord(ev_stop[ev_used], stream));
+    ev_used += 1;
+}
+
 void Smoother::apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega) {
     exchange(const_cast<double2*>(in));
     for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
@@ -337,21 +373,7 @@ void Smoother::apply(const double2* in, double2* out, int mode, int dot, const d
         a.nj = static_cast<int>(topo.nj[b]);
         a.omega = omega;
         a.partials = partials + static_cast<size_t>(poff[k]) * MAX_PARTIALS;
-        if (profile) {
-            if (ev_used == ev_start.size()) {
-                hipEvent_t e0, e1;
-                HIPCHK(hipEventCreate(&e0));
-                HIPCHK(hipEventCreate(&e1));
-                ev_start.push_back(e0);
-                ev_stop.push_back(e1);
-            }
-            HIPCHK(hipEventRecord(ev_start[ev_used], stream));
-            HIPCHK(launch_apply_block(a, mode, dot, stream));
-            HIPCHK(hipEventRecord(ev_stop[ev_used], stream));
-            ev_used += 1;
-        } else {
-            HIPCHK(launch_apply_block(a, mode, dot, stream));
-        }
+        profiled([&]() { HIPCHK(launch_apply_block(a, mode, dot, stream)); });
     }
     exchange_finish();   // K2 above read owned rows only; the perimeter rows below read the ghost rows
     HIPCHK(launch_edge_rows(edge, in, xk, PQ, aux, out, omega, mode, dot, partials + static_cast<size_t>(poff_edge) * MAX_PARTIALS, stream));
@@ -455,8 +477,44 @@ int Smoother::picard_bicgstab(tm_stats& st) {
     return converged ? 0 : 1;
 }
 
+// Two sweeps in one pass over the interior rows: X^(k+2) = S(S(X^k)), bit-identical to two single sweeps.
+//   perimeter rows of X^(k+1)  <- perimeter-row kernel on X^k           (into M)
+//   interior rows of X^(k+2)   <- K2x2 (reads X^k and M's perimeter; leaves the first-interior ring of X^(k+1) in M)
+//   perimeter rows of X^(k+2)  <- perimeter-row kernel on M (perimeter + ring + exchanged ghost rows are all it reads)
+void Smoother::relax_pair() {
+    exchange(X);
+    exchange_finish();
+    HIPCHK(launch_edge_rows(edge, X, X, PQ, nullptr, M, opt.omega, MODE_RELAX, DOT_NONE, partials, stream));
+    for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
+        const int64_t b = lp.owned_blocks[k];
+        const int64_t ls = lp.local_start[k];
+        Relax2Block a;
+        a.in = X + ls;
+        a.mid = M + ls;
+        a.out = U + ls;
+        a.ni = static_cast<int>(topo.ni[b]);
+        a.nj = static_cast<int>(topo.nj[b]);
+        a.omega = opt.omega;
+        a.partials = partials + static_cast<size_t>(poff2[k]) * MAX_PARTIALS;
+        profiled([&]() { HIPCHK(launch_relax2_block(a, rows2[k], DOT_DELTA, stream)); });
+    }
+    exchange(M);
+    exchange_finish();
+    HIPCHK(launch_edge_rows(edge, M, M, PQ, nullptr, U, opt.omega, MODE_RELAX, DOT_DELTA, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, stream));
+    std::swap(X, U);
+}
+
 void Smoother::relax_sweeps(uint64_t n, tm_stats& st) {
-    for (uint64_t k = 0; k < n; ++k) {
+    int last_nwg = nwg_apply;
+    uint64_t k = 0;
+    for (; fuse_pairs && k + 2 <= n; k += 2) {
+        relax_pair();
+        st.operator_sweeps += 2;
+        outer_done += 2;
+        last_nwg = nwg_apply2;
+    }
+    for (; k < n; ++k) {
+        last_nwg = nwg_apply;
         if (white && outer_done > 0) white_launch(1);
         // one fused sweep: U = X + omega D^-1 (b - A(X) X), partial sums of (U - X)^2
         apply(X, U, MODE_RELAX, DOT_DELTA, nullptr, X, opt.omega);
@@ -465,7 +523,7 @@ void Smoother::relax_sweeps(uint64_t n, tm_stats& st) {
         outer_done += 1;
     }
     if (n) {
-        reduce(nwg_apply);   // partial sums of the LAST sweep -> sum (x_old - x_new)^2, sum (y_old - y_new)^2
+        reduce(last_nwg);   // partial sums of the LAST sweep -> sum (x_old - x_new)^2, sum (y_old - y_new)^2
         HIPCHK(hipMemcpyAsync(h_red, red, sizeof(double) * MAX_PARTIALS, hipMemcpyDeviceToHost, stream));
         sync();
         st.last_dx2 = h_red[0];

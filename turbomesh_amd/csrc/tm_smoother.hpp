@@ -5,6 +5,7 @@
 #include "tm_plan.hpp"
 #include <memory>
 #include <string>
+#include <functional>
 #include <vector>
 
 namespace tmh {
@@ -51,6 +52,8 @@ struct Smoother {
     // vectors, double2[n_local]
     double2 *X = nullptr, *U = nullptr, *r = nullptr, *r_hat = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *t = nullptr;
     double2 *PQ = nullptr, *tmpA = nullptr, *tmpB = nullptr;
+    double2* M = nullptr;           // X^(k+1) of a fused pair of relax sweeps (perimeter + first-interior ring only)
+    bool fuse_pairs = false;
     // perimeter rows
     EdgeRowsDev edge;
     std::vector<double> h_rhs;   // host copy of the static rhs (refilled on upload)
@@ -63,6 +66,8 @@ struct Smoother {
     double* h_red = nullptr;        // pinned
     std::vector<int> poff;          // partial-row offset of each owned block's K2 launch
     int poff_edge = 0, nwg_apply = 0, nwg_vec = 0;
+    std::vector<int> poff2, rows2;  // same for the fused two-sweep launches, and their rows per workgroup
+    int poff2_edge = 0, nwg_apply2 = 0;
     // halo exchange
     int32_t* d_send_ids = nullptr;
     double2* d_send_buf = nullptr;
@@ -99,6 +104,8 @@ struct Smoother {
    private:
     int picard_bicgstab(tm_stats& st);
     void relax_sweeps(uint64_t n, tm_stats& st);
+    void relax_pair();
+    void profiled(const std::function<void()>& launch);
 };
 
 }  // namespace tmh

@@ -220,6 +220,7 @@ struct Option {
     double rtol = 0, atol = 0, omega = 0;
     uint64_t max_inner = 0;
     uint32_t check_every = 0;
+    bool single_sweep = false;
 };
 }  // namespace solver
 namespace wall_control_function {               // wall_control_function.zig:10-20, 56-68
@@ -254,7 +255,7 @@ inline tm_stats mesh(discrete::Mesh& mesh_data, std::size_t iterations, const so
     for (const auto& b : mesh_data.boundary_conditions) bcs.push_back(tm_condition{detail::toRange(b.range), static_cast<uint32_t>(b.kind), 0});
     tm_mesh_desc desc{blocks.data(), blocks.size(), conns.data(), conns.size(), bcs.data(), bcs.size()};
     tm_solver_opt so{static_cast<int32_t>(solver_option.tag), solver_option.inner, solver_option.rtol, solver_option.atol, solver_option.max_inner,
-                     solver_option.check_every, 0, solver_option.omega};
+                     solver_option.check_every, solver_option.single_sweep ? uint32_t{TM_OPT_SINGLE_SWEEP} : 0u, solver_option.omega};
     tm_control_fn cf{TM_CF_LAPLACE, 0, 0.0, 0.0};
     if (control_function_algorithm.white) cf = tm_control_fn{TM_CF_WHITE, 0, control_function_algorithm.white->ds_target, control_function_algorithm.white->theta_target};
     tm_stats st{};

@@ -46,10 +46,12 @@ class Option:
     max_inner: int = 0         # 0 -> 1000 (BiCGStab.zig:19)
     check_every: int = 0       # 0 -> 8
     omega: float = 0.0         # 0 -> 1.0
+    single_sweep: bool = False # relax: one kernel pass per sweep (default: two sweeps per pass where possible)
 
     @classmethod
     def hip(cls, **kw):
         return cls(tag=Tag.hip, **kw)
 
     def c_struct(self):
-        return _capi.tm_solver_opt(int(self.tag), int(self.inner), self.rtol, self.atol, self.max_inner, self.check_every, 0, self.omega)
+        return _capi.tm_solver_opt(int(self.tag), int(self.inner), self.rtol, self.atol, self.max_inner, self.check_every,
+                                   1 if self.single_sweep else 0, self.omega)
