@@ -180,6 +180,10 @@ def main():
                          "kernel": "k_relax2<DELTA> (K2x2: two winslow sweeps per launch)" if fused else "k_apply<RELAX,DELTA,field,laplace> (K2 winslow_apply)",
                          "sweeps_per_launch": sweeps_per_launch, "bytes_per_launch_algorithmic": bytes_per_launch,
                          "hbm_GBps_measured_traffic": (traffic / k2_avg_s / 1e9) if traffic else None,
+                         "frac_measured_traffic": (traffic / k2_avg_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
+                         "note": ("achieved = SURVEY 8d accounting (32 B per node per sweep) x 2 sweeps per launch; the launch moves the field "
+                                  "through HBM once for both sweeps (see traffic), so achieved may exceed the HBM peak; co-limited by fp64 VALU issue")
+                         if fused else "one sweep per launch",
                          "avg_launch_us": k2_avg_s * 1e6, "launches": k2_launches,
                          "timing": "hipEvent pairs around every K2 launch on the handle's stream, inside the timed region"},
         }

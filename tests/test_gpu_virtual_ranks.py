@@ -116,6 +116,8 @@ def _run_ranks(builder, owner, option, iterations, rounds=1, hooks_cls=None):
     ("strip4", lambda: configs.strip(4, 17, 24, reverse_odd=True), [0, 1, 0, 1]),
     ("strip3", lambda: configs.strip(3, 40, 300), [0, 1, 2]),
     ("two_by_two", lambda: configs.two_by_two(12, 14), [0, 1, 1, 0]),
+    # large enough that the split two-sweep pass has workgroups in all three parts (border / inside A / inside B)
+    ("strip2_big", lambda: configs.strip(2, 200, 700, reverse_odd=True), [0, 1]),
 ])
 def test_multi_rank_equals_single_rank(name, builder, owner):
     from turbomesh_amd.smoothing import smooth

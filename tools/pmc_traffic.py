@@ -5,7 +5,7 @@
 gfx950 corrections applied as that guide prescribes: FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE reports exactly
 half of the bytes of a wide (16 B/lane) coalesced streaming read -> doubled; WRITE_SIZE is exact for 16 B/lane streaming stores.
 
-usage: pmc_traffic.py <dir with FETCH_SIZE run> <dir with WRITE_SIZE run> <n> <out.json>"""
+usage: pmc_traffic.py <dir with FETCH_SIZE run> <dir with WRITE_SIZE run> <n> <out.json> [kernel substring = k_relax2] [sweeps per launch = 2]"""
 import csv
 import glob
 import json
@@ -13,30 +13,32 @@ import sys
 
 
 def mean_counter(d, name, kernel="k_apply"):
-    f = glob.glob(d + "/*/*_counter_collection.csv")[0]
+    f = glob.glob(d + "/**/*_counter_collection.csv", recursive=True)[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"] and r["Counter_Name"] == name]
     return sum(vals) / len(vals), len(vals)
 
 
 def mean_duration_us(d, kernel="k_apply"):
-    f = glob.glob(d + "/*/*_kernel_trace.csv")[0]
+    f = glob.glob(d + "/**/*_kernel_trace.csv", recursive=True)[0]
     ds = [(int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e3 for r in csv.DictReader(open(f)) if kernel in r["Kernel_Name"]]
     return sum(ds) / len(ds)
 
 
 if __name__ == "__main__":
     dfetch, dwrite, n, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-    fetch_kib, nf = mean_counter(dfetch, "FETCH_SIZE")
-    write_kib, nw = mean_counter(dwrite, "WRITE_SIZE")
+    kern = sys.argv[5] if len(sys.argv) > 5 else "k_relax2"
+    spl = int(sys.argv[6]) if len(sys.argv) > 6 else (2 if kern == "k_relax2" else 1)
+    fetch_kib, nf = mean_counter(dfetch, "FETCH_SIZE", kern)
+    write_kib, nw = mean_counter(dwrite, "WRITE_SIZE", kern)
     read_bytes = 2.0 * fetch_kib * 1024.0
     write_bytes = write_kib * 1024.0
     res = {
-        "n": n, "kernel": "k_apply (K2 winslow_apply, relax sweep)", "launches_sampled": [nf, nw],
+        "n": n, "kernel": kern, "sweeps_per_launch": spl, "launches_sampled": [nf, nw],
         "FETCH_SIZE_KiB": fetch_kib, "WRITE_SIZE_KiB": write_kib,
         "hbm_read_bytes_per_launch": read_bytes, "hbm_write_bytes_per_launch": write_bytes,
-        "hbm_bytes_per_launch": read_bytes + write_bytes, "algorithmic_bytes_per_launch": 32.0 * n * n,
-        "ratio_to_algorithmic": (read_bytes + write_bytes) / (32.0 * n * n),
-        "avg_kernel_us_under_pmc": [mean_duration_us(dfetch), mean_duration_us(dwrite)],
+        "hbm_bytes_per_launch": read_bytes + write_bytes, "algorithmic_bytes_per_launch": 32.0 * n * n * spl,
+        "ratio_to_algorithmic": (read_bytes + write_bytes) / (32.0 * n * n * spl),
+        "avg_kernel_us_under_pmc": [mean_duration_us(dfetch, kern), mean_duration_us(dwrite, kern)],
         "corrections": "FETCH_SIZE x2 (gfx950 reports half of a wide coalesced read), KiB -> bytes; separate --pmc passes",
     }
     json.dump(res, open(out, "w"), indent=1)

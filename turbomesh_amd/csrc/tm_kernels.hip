@@ -168,6 +168,27 @@ __device__ __forceinline__ void accumulate(double (&acc)[MAX_PARTIALS], double2 
 // oracle's mirror of this very sequence (oracle/orc_mirror.cpp): every fma below is explicit,
 // everything else is built with -ffp-contract=off.
 // ------------------------------------------------------------------------------------------
+// rinv = (D == 0) ? 0.25 : 1.0 / m2D, correctly rounded (the oracle's mirror divides with IEEE `/`).
+// hipcc expands an f64 division into div_scale x2, rcp, the Newton/Markstein chain (5 fma + 1 mul), div_fmas and div_fixup.
+// With numerator 1 and a denominator whose exponent is far from the ends of the range, the scalings are the identity and
+// the fix-up passes the value through, so the chain alone -- v_rcp_f64 + 6 fma -- returns the same bits; that covers every
+// mesh whose squared spacings lie in [2^-700, 2^700].  Anything else (D == 0, subnormal / huge / non-finite spacings) takes
+// the full division; the choice is wave-uniform, so the common case pays two compares and no select.
+__device__ __forceinline__ double recip_diag(double D, double m2D) {
+    const bool plain = (D >= 0x1p-700) && (D <= 0x1p700);
+    if (__builtin_amdgcn_ballot_w64(!plain) == 0) {
+        const double nd = -m2D;
+        const double r0 = __builtin_amdgcn_rcp(m2D);
+        const double e0 = fma(nd, r0, 1.0);
+        const double r1 = fma(r0, e0, r0);
+        const double e1 = fma(nd, r1, 1.0);
+        const double r2 = fma(r1, e1, r1);
+        const double e2 = fma(nd, r2, 1.0);   // residual of the quotient 1 * r2
+        return fma(e2, r2, r2);
+    }
+    return (D == 0.0) ? 0.25 : 1.0 / m2D;
+}
+
 // A row of the vector enters as (c, e, h): the value and, from the two lane shifts done once when the row is loaded,
 // e = w(i,j+1) - w(i,j-1) and h = w(i,j+1) + w(i,j-1).  The cross term is k = e(i+1) - e(i-1).
 // dxi = xk(i+1,j) - xk(i-1,j), det = xk(i,j+1) - xk(i,j-1): the frozen field's differences (field mode: p_c - m_c and e_c).
@@ -199,7 +220,7 @@ __device__ __forceinline__ double2 winslow_row(double2 m_c, double2 e_m, double2
     sx = fma(mhG12, kx, sx);
     sy = fma(mhG12, ky, sy);   // sx, sy = 4 * (A w)_row
     if (MODE == MODE_RAW) return make_double2(0.25 * sx, 0.25 * sy);
-    const double rinv = (D == 0.0) ? 0.25 : 1.0 / m2D;   // 1 / (4 a_ii); a_ii == 0 -> D^-1 := 1 (BiCGStab.zig:169-173)
+    const double rinv = recip_diag(D, m2D);   // 1 / (4 a_ii); a_ii == 0 -> D^-1 := 1 (BiCGStab.zig:169-173)
     const double tx = sx * rinv, ty = sy * rinv;          // (D^-1 A w)_row
     if (MODE == MODE_SCALED) return make_double2(tx, ty);
     if (MODE == MODE_RESID) return make_double2(-tx, -ty);   // b = 0 on interior rows
@@ -540,7 +561,7 @@ __device__ __forceinline__ void relax2_strip_inside(const Relax2Block& a, const 
 }
 
 template <int DOT, int U, bool NT, bool W1>
-__global__ __launch_bounds__(256) void k_relax2(Relax2Block a, int RI, int nSG, int nRC) {
+__global__ __launch_bounds__(256) void k_relax2(Relax2Block a, int RI, int nSG, int nRC, int subset) {
     static_assert(U % 3 == 0, "windows rotate by renaming");
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -559,6 +580,11 @@ __global__ __launch_bounds__(256) void k_relax2(Relax2Block a, int RI, int nSG, 
     t.i0 = 1 + rc * RI;
     t.i1 = min(t.i0 + RI, ni - 1);
 
+    if (subset != R2_ALL) {   // workgroup-uniform: this launch runs only part of the tiles (see Relax2Subset)
+        const bool wg_inside = (sg * 240 >= 4) && ((sg * 4 + 3) * 60 + 61 <= nj - 3) && (t.i0 >= 4) && (t.i1 + 1 <= ni - 3);
+        const bool mine = (subset == R2_BORDER) ? !wg_inside : (wg_inside && ((subset == R2_INSIDE_A) == (rc < nRC / 2)));
+        if (!mine) return;   // its partial sums are written by the launch that does run it
+    }
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
     if (t.c0 <= nj - 2 && t.i0 < t.i1) {   // wave-uniform
         // strictly inside: columns c0-2 .. c0+61 within [2, nj-3], rows i0-2 .. i1+1 within [2, ni-3] -> no perimeter, no ring
@@ -572,8 +598,10 @@ __global__ __launch_bounds__(256) void k_relax2(Relax2Block a, int RI, int nSG, 
 static int g_fuse_rows = 0;   // 0 = choose per block (relax2_rows_per_chunk); > 0 = forced (tm_tune_fuse)
 constexpr int R2_U = 3;      // rows per load group of k_relax2
 
-// Rows per chunk of K2x2.  A workgroup (4 strips x RI rows) runs RI+2 steps and the CU holds 4 of them (104 VGPRs), so the
-// launch proceeds in rounds of 4 x #CU workgroups: pick the RI (a multiple of the load group) that minimises rounds x steps.
+// Rows per chunk of K2x2.  Short chunks win on the MI355X although every chunk re-reads 4 rows: with several times more
+// workgroups than the 4 x #CU that fit at once, their load-heavy prologues and arithmetic-heavy steady states interleave in
+// time instead of marching in lockstep (measured at 4096^2: 18 rows 110 us, 36 rows 116 us, 75 rows = one round 125 us,
+// 150 rows 138 us).  18 rows, fewer when the block is too small to fill the device even then.
 int relax2_rows_per_chunk(int ni, int nj) {
     const int interior = ni - 2;
     if (g_fuse_rows > 0) return std::max(1, std::min(g_fuse_rows, interior));
@@ -584,36 +612,26 @@ int relax2_rows_per_chunk(int ni, int nj) {
         slots = 4 * cus;
     }
     const int nstrips = (nj - 1 + 59) / 60, nSG = (nstrips + 3) / 4;
-    long best_cost = -1;
-    int best = R2_U;
-    for (int RI = 4 * R2_U; RI <= 64 * R2_U; RI += R2_U) {
-        const long nRC = (interior + RI - 1) / RI;
-        const long rounds = (nSG * nRC + slots - 1) / slots;
-        const long cost = rounds * (RI + 2 + 4);   // + prologue / epilogue of a workgroup, in steps
-        if (best_cost < 0 || cost <= best_cost) {
-            best_cost = cost;
-            best = RI;
-        }
-        if (RI >= interior) break;
-    }
-    return best;
+    int RI = 6 * R2_U;
+    while (RI > 4 * R2_U && static_cast<long>(nSG) * ((interior + RI - 1) / RI) < slots) RI -= R2_U;
+    return std::max(1, std::min(RI, interior));
 }
 bool relax2_supported(int ni, int nj) { return ni >= 5 && nj >= 5 && nj <= (1 << 20); }   // buffer-store offsets: rows_per_chunk * nj * 16 < 2^31
 int relax2_block_nwg(int ni, int nj, int RI) {
     const int nstrips = (nj - 1 + 59) / 60;
     return ((nstrips + 3) / 4) * ((ni - 2 + RI - 1) / RI);
 }
-hipError_t launch_relax2_block(const Relax2Block& a, int RI, int dot, hipStream_t st) {
+hipError_t launch_relax2_block(const Relax2Block& a, int RI, int dot, int subset, hipStream_t st) {
     const int nstrips = (a.nj - 1 + 59) / 60;
     const int nSG = (nstrips + 3) / 4, nRC = (a.ni - 2 + RI - 1) / RI;
     const dim3 grid(nSG * nRC), block(256);
     const bool w1 = a.omega == 1.0;
     if (dot == DOT_DELTA) {
-        if (w1) hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, true>), grid, block, 0, st, a, RI, nSG, nRC);
-        else hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, false>), grid, block, 0, st, a, RI, nSG, nRC);
+        if (w1) hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, true>), grid, block, 0, st, a, RI, nSG, nRC, subset);
+        else hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, false>), grid, block, 0, st, a, RI, nSG, nRC, subset);
     } else {
-        if (w1) hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, true, true>), grid, block, 0, st, a, RI, nSG, nRC);
-        else hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, true, false>), grid, block, 0, st, a, RI, nSG, nRC);
+        if (w1) hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, true, true>), grid, block, 0, st, a, RI, nSG, nRC, subset);
+        else hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, true, false>), grid, block, 0, st, a, RI, nSG, nRC, subset);
     }
     return hipGetLastError();
 }

@@ -340,7 +340,7 @@ void Smoother::reduce(int nwg) {
 }
 
 // runs `launch`; with profiling on, bracketed by a hipEvent pair on the handle's stream
-void Smoother::profiled(const std::function<void()>& launch) {
+void Smoother::profiled(const std::function<void()>& launch, bool counts) {
     if (!profile) {
         launch();
         return;
@@ -356,6 +356,7 @@ void Smoother::profiled(const std::function<void()>& launch) {
     launch();
     HIPCHK(hipEventRecord(ev_stop[ev_used], stream));
     ev_used += 1;
+    if (counts) prof_launches += 1;
 }
 
 void Smoother::apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega) {
@@ -481,10 +482,9 @@ int Smoother::picard_bicgstab(tm_stats& st) {
 //   perimeter rows of X^(k+1)  <- perimeter-row kernel on X^k           (into M)
 //   interior rows of X^(k+2)   <- K2x2 (reads X^k and M's perimeter; leaves the first-interior ring of X^(k+1) in M)
 //   perimeter rows of X^(k+2)  <- perimeter-row kernel on M (perimeter + ring + exchanged ghost rows are all it reads)
-void Smoother::relax_pair() {
-    exchange(X);
-    exchange_finish();
-    HIPCHK(launch_edge_rows(edge, X, X, PQ, nullptr, M, opt.omega, MODE_RELAX, DOT_NONE, partials, stream));
+// With several ranks the K2x2 grid is launched in three parts so that both halo exchanges (of X^k, then of X^(k+1)) travel
+// while workgroups that touch neither perimeter nor ring are running.
+void Smoother::relax2_launch(int subset, bool counts) {
     for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
         const int64_t b = lp.owned_blocks[k];
         const int64_t ls = lp.local_start[k];
@@ -496,9 +496,19 @@ void Smoother::relax_pair() {
         a.nj = static_cast<int>(topo.nj[b]);
         a.omega = opt.omega;
         a.partials = partials + static_cast<size_t>(poff2[k]) * MAX_PARTIALS;
-        profiled([&]() { HIPCHK(launch_relax2_block(a, rows2[k], DOT_DELTA, stream)); });
+        profiled([&]() { HIPCHK(launch_relax2_block(a, rows2[k], DOT_DELTA, subset, stream)); }, counts);
     }
+}
+
+void Smoother::relax_pair() {
+    const bool split = has_hooks && (n_send > 0 || n_ghost > 0);
+    exchange(X);
+    if (split) relax2_launch(R2_INSIDE_A, false);
+    exchange_finish();
+    HIPCHK(launch_edge_rows(edge, X, X, PQ, nullptr, M, opt.omega, MODE_RELAX, DOT_NONE, partials, stream));
+    relax2_launch(split ? R2_BORDER : R2_ALL, true);
     exchange(M);
+    if (split) relax2_launch(R2_INSIDE_B, false);
     exchange_finish();
     HIPCHK(launch_edge_rows(edge, M, M, PQ, nullptr, U, opt.omega, MODE_RELAX, DOT_DELTA, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, stream));
     std::swap(X, U);
@@ -561,8 +571,9 @@ void Smoother::profile_read(double* ms_total, uint64_t* launches) {
         total += ms;
     }
     if (ms_total) *ms_total = total;
-    if (launches) *launches = ev_used;
+    if (launches) *launches = prof_launches;
     ev_used = 0;
+    prof_launches = 0;
 }
 
 // ------------------------------------------------------------------ introspection

@@ -80,6 +80,7 @@ struct Smoother {
     bool profile = false;
     std::vector<hipEvent_t> ev_start, ev_stop;
     size_t ev_used = 0;
+    uint64_t prof_launches = 0;     // event pairs that count as a launch of the dominant kernel (the parts of a split K2x2 pass count once)
     void profile_read(double* ms_total, uint64_t* launches);
 
     void create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm_control_fn* c, const tm_comm_hooks* h, void* strm,
@@ -105,7 +106,8 @@ struct Smoother {
     int picard_bicgstab(tm_stats& st);
     void relax_sweeps(uint64_t n, tm_stats& st);
     void relax_pair();
-    void profiled(const std::function<void()>& launch);
+    void profiled(const std::function<void()>& launch, bool counts = true);
+    void relax2_launch(int subset, bool counts);
 };
 
 }  // namespace tmh
