@@ -66,6 +66,8 @@ def main():
     ap.add_argument("--size", dest="n", type=int, default=4096, help="block edge (nodes); 4096 is the BASELINE config")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (RCCL hooks) even with one rank")
+    ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
+                    help="halo exchange: the library's own RCCL transport (default) or torch.distributed p2p from Python hooks")
     ap.add_argument("--rows", type=int, default=0, help="K2 rows per chunk (tuning)")
     ap.add_argument("--unroll", type=int, default=0, help="K2 row unroll (tuning)")
     ap.add_argument("--pipe", type=int, default=-1, help="K2 software pipelining 0/1 (tuning)")
@@ -121,10 +123,36 @@ def main():
         from turbomesh_amd import distributed as tmd
 
         mesh = tmd.strip_for_rank(world, rank, n, n)                        # only the owned block carries coordinates
-        hooks_obj = tmd.TorchHooks(mesh, owner=list(range(world)), rank=rank, world=world,
-                                   option=relax_opt)
+        owner = list(range(world))
+        transport = "torch.distributed p2p (Python hooks)"
+        if backend == "nccl" and args.transport == "rccl":
+            # the library's own RCCL transport; checked once against the torch.distributed hooks on a small strip
+            # (same sweeps, bit-identical coordinates expected) -- every rank takes the same decision
+            ok, why = 1, ""
+            try:
+                small = [tmd.strip_for_rank(world, rank, 192, 256) for _ in range(2)]
+                h_a = tmd.RcclHooks(small[0], owner=owner, rank=rank, world=world, option=relax_opt)
+                h_b = tmd.TorchHooks(small[1], owner=owner, rank=rank, world=world, option=relax_opt)
+                for h in (h_a, h_b):
+                    h.iterate(5)
+                    h.smoother.download()
+                ok = int(np.array_equal(small[0].blocks[rank].points.data, small[1].blocks[rank].points.data))
+                why = "" if ok else "coordinates differ from the torch.distributed transport"
+                h_a.close()
+                h_b.smoother.close()
+            except Exception as e:   # noqa: BLE001 -- any failure means: use the other transport
+                ok, why = 0, repr(e)
+            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                hooks_obj = tmd.RcclHooks(mesh, owner=owner, rank=rank, world=world, option=relax_opt)
+                transport = "RCCL p2p issued by libtm_hip (tm_rccl_*)"
+            else:
+                print(f"[bench] rank {rank}: native RCCL transport not used ({why or 'another rank declined'})", file=sys.stderr)
+        if hooks_obj is None:
+            hooks_obj = tmd.TorchHooks(mesh, owner=owner, rank=rank, world=world, option=relax_opt)
         sm = hooks_obj.smoother
-        workload = f"strip of {world} blocks {n}x{n}, one per GPU, interface rows exchanged by RCCL p2p every sweep"
+        workload = f"strip of {world} blocks {n}x{n}, one per GPU, interface rows exchanged by {transport} every sweep"
     else:
         mesh = configs.single_block(n, n)                                   # TFI on the GPU (K1)
         sm = smooth.Smoother(mesh, relax_opt, stream=torch.cuda.current_stream().cuda_stream)

@@ -196,6 +196,20 @@ int tm_smoother_download(tm_smoother* s, const tm_mesh_desc* mesh);
 int tm_smoother_upload(tm_smoother* s, const tm_mesh_desc* mesh);
 void tm_smoother_destroy(tm_smoother* s);
 
+/* Built-in transport for the hooks above: RCCL point-to-point (xGMI) + all-reduce issued by the library itself, so that no
+ * host-language callback sits in the sweep loop.  librccl is dlopen'ed: pass the path of the copy the process already uses
+ * (e.g. <torch>/lib/librccl.so) or NULL for the default search.  Rank 0 calls tm_rccl_unique_id and hands the 128 bytes
+ * to the other ranks by whatever rendezvous the host has (torch.distributed broadcast, MPI, a file); every rank then calls
+ * tm_rccl_comm_create (collective) with the current HIP device set.  tm_rccl_hooks fills `hooks` for a mesh partition:
+ * exchange/exchange_wait = grouped ncclRecv/ncclSend per neighbouring rank on a side stream, fenced with events against
+ * the handle's stream; allreduce_sum = ncclAllReduce.  The hooks (and hooks->owner) stay valid while `comm` lives. */
+typedef struct tm_rccl_comm tm_rccl_comm;
+#define TM_RCCL_ID_BYTES 128
+int tm_rccl_unique_id(const char* librccl_path, void* id_out /* TM_RCCL_ID_BYTES */);
+int tm_rccl_comm_create(const char* librccl_path, const void* id, int32_t rank, int32_t nranks, tm_rccl_comm** out);
+void tm_rccl_comm_destroy(tm_rccl_comm* comm);
+int tm_rccl_hooks(tm_rccl_comm* comm, const tm_mesh_desc* mesh, const int32_t* owner /* [nblocks] */, tm_comm_hooks* hooks);
+
 /* Exchange plan of a handle created with hooks: npeers peers; for peer k, send_count[k] rows
  * (16 B each) start at send_offset[k] rows into send_buf, same for recv.  Rows are double2. */
 int tm_smoother_exchange_plan(const tm_smoother* s, int32_t* npeers, const int32_t** peer_rank,

@@ -8,27 +8,7 @@
 
 using namespace tmh;
 
-static thread_local std::string g_last_error;
-
-template <class F>
-static int guarded(F&& f) {
-    try {
-        return f();
-    } catch (const TmError& e) {
-        g_last_error = e.what();
-        return e.code;
-    } catch (const PlanError& e) {
-        g_last_error = e.what();
-        return e.code;
-    } catch (const std::bad_alloc&) {
-        g_last_error = "out of host memory";
-        return TM_E_MEMORY;
-    } catch (const std::exception& e) {
-        g_last_error = e.what();
-        return TM_E_ARG;
-    }
-}
-#define HIPCHK(x) hip_check((x), #x)
+#include "tm_api_util.hpp"
 
 static void require_gfx950() {
     static int checked = 0;
@@ -56,30 +36,6 @@ struct DevBuf {
 };
 
 static bool close2(const double* a, const double* b, double tol) { return std::fabs(a[0] - b[0]) <= tol && std::fabs(a[1] - b[1]) <= tol; }
-
-static Topology topo_of(const tm_mesh_desc* mesh) {
-    Topology t;
-    if (!mesh || !mesh->blocks || mesh->nblocks == 0) throw TmError(TM_E_ARG, "mesh description without blocks");
-    for (uint64_t b = 0; b < mesh->nblocks; ++b) {
-        t.ni.push_back(static_cast<int64_t>(mesh->blocks[b].ni));
-        t.nj.push_back(static_cast<int64_t>(mesh->blocks[b].nj));
-    }
-    auto rng = [](const tm_range& r) {
-        return TopoRange{static_cast<int64_t>(r.block), r.side, static_cast<int64_t>(r.start), static_cast<int64_t>(r.end)};
-    };
-    for (uint64_t c = 0; c < mesh->nconns; ++c) {
-        TopoConn tc;
-        tc.r[0] = rng(mesh->conns[c].r[0]);
-        tc.r[1] = rng(mesh->conns[c].r[1]);
-        tc.periodic = mesh->conns[c].has_periodicity != 0;
-        tc.per[0] = mesh->conns[c].periodicity[0];
-        tc.per[1] = mesh->conns[c].periodicity[1];
-        t.conns.push_back(tc);
-    }
-    for (uint64_t c = 0; c < mesh->nbcs; ++c) t.bcs.push_back(TopoCond{rng(mesh->bcs[c].range), mesh->bcs[c].kind});
-    t.finalize();
-    return t;
-}
 
 template <class T>
 static T* dup(const std::vector<T>& v) {

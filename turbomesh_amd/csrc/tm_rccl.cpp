@@ -1,0 +1,212 @@
+// Built-in transport behind tm_comm_hooks: RCCL point-to-point (over xGMI) and all-reduce, issued by the library itself.
+//
+// The halo exchange of a sweep is two small messages per neighbour (interface row + first-interior row, 2 x 64 KiB at
+// 4096 columns).  Issued from a host-language callback that costs ~50-70 us per exchange (measured with
+// torch.distributed's batch_isend_irecv, tools/ubench/p2p_host_cost.py), which is more than half of what the GPU needs for
+// the two sweeps in between; issued from here it is a grouped ncclSend/ncclRecv on a side stream plus two events.
+//
+// librccl is loaded at run time (dlopen) so that the process uses ONE RCCL -- the copy the host framework already loaded,
+// when there is one (the caller passes its path) -- and so that libtm_hip.so has no link-time dependency on it.
+#include "tm_api_util.hpp"
+#include "tm_plan.hpp"
+
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+
+#include <cstring>
+#include <memory>
+#include <mutex>
+#include <string>
+#include <vector>
+
+namespace tmh {
+
+// ---- the few RCCL declarations used (rccl.h: ncclUniqueId is 128 opaque bytes; ncclFloat64 = 8, ncclSum = 0)
+struct NcclUniqueId {
+    char internal[128];
+};
+typedef struct ncclComm* NcclComm;
+enum { NCCL_SUCCESS = 0, NCCL_FLOAT64 = 8, NCCL_SUM = 0 };
+
+struct RcclApi {
+    void* handle = nullptr;
+    int (*GetUniqueId)(NcclUniqueId*) = nullptr;
+    int (*CommInitRank)(NcclComm*, int, NcclUniqueId, int) = nullptr;
+    int (*CommDestroy)(NcclComm) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    int (*Send)(const void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*Recv)(void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, NcclComm, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+
+static RcclApi g_rccl;
+static std::mutex g_rccl_mutex;
+
+static RcclApi& rccl_api(const char* path) {
+    std::lock_guard<std::mutex> lock(g_rccl_mutex);
+    if (g_rccl.handle) return g_rccl;
+    const char* candidates[] = {path, "librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so"};
+    std::string tried;
+    for (const char* c : candidates) {
+        if (!c || !*c) continue;
+        g_rccl.handle = dlopen(c, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.handle) break;
+        tried += std::string(c) + ": " + dlerror() + "; ";
+    }
+    if (!g_rccl.handle) throw TmError(TM_E_COMM, "cannot load librccl (" + tried + ")");
+    auto sym = [&](const char* name) {
+        void* p = dlsym(g_rccl.handle, name);
+        if (!p) throw TmError(TM_E_COMM, std::string("librccl lacks ") + name);
+        return p;
+    };
+    g_rccl.GetUniqueId = reinterpret_cast<decltype(g_rccl.GetUniqueId)>(sym("ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<decltype(g_rccl.CommInitRank)>(sym("ncclCommInitRank"));
+    g_rccl.CommDestroy = reinterpret_cast<decltype(g_rccl.CommDestroy)>(sym("ncclCommDestroy"));
+    g_rccl.GroupStart = reinterpret_cast<decltype(g_rccl.GroupStart)>(sym("ncclGroupStart"));
+    g_rccl.GroupEnd = reinterpret_cast<decltype(g_rccl.GroupEnd)>(sym("ncclGroupEnd"));
+    g_rccl.Send = reinterpret_cast<decltype(g_rccl.Send)>(sym("ncclSend"));
+    g_rccl.Recv = reinterpret_cast<decltype(g_rccl.Recv)>(sym("ncclRecv"));
+    g_rccl.AllReduce = reinterpret_cast<decltype(g_rccl.AllReduce)>(sym("ncclAllReduce"));
+    g_rccl.GetErrorString = reinterpret_cast<decltype(g_rccl.GetErrorString)>(sym("ncclGetErrorString"));
+    return g_rccl;
+}
+
+static void nccl_check(int rc, const char* what) {
+    if (rc != NCCL_SUCCESS) throw TmError(TM_E_COMM, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"));
+}
+
+}  // namespace tmh
+
+using namespace tmh;
+
+// One communicator of the job + the side stream its transfers run on.
+struct tm_rccl_comm {
+    NcclComm comm = nullptr;
+    int32_t rank = 0, nranks = 1;
+    hipStream_t stream = nullptr;       // transfers run here, beside the handle's compute stream
+    hipEvent_t ready = nullptr, done = nullptr;
+    // exchange pattern of the partition given to tm_rccl_hooks (rows are double2)
+    std::vector<int32_t> owner, peer;
+    std::vector<int64_t> send_off, send_cnt, recv_off, recv_cnt;
+};
+
+namespace {
+
+int rccl_exchange(void* ctx, const double* send_buf, double* recv_buf, void* stream) {
+    tm_rccl_comm* c = static_cast<tm_rccl_comm*>(ctx);
+    try {
+        if (c->peer.empty()) return 0;
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        HIPCHK(hipEventRecord(c->ready, s));   // the pack kernel has filled send_buf
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ready, 0));
+        nccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+        for (size_t k = 0; k < c->peer.size(); ++k) {
+            if (c->recv_cnt[k])
+                nccl_check(g_rccl.Recv(recv_buf + 2 * c->recv_off[k], static_cast<size_t>(2 * c->recv_cnt[k]), NCCL_FLOAT64, c->peer[k], c->comm, c->stream), "ncclRecv");
+            if (c->send_cnt[k])
+                nccl_check(g_rccl.Send(send_buf + 2 * c->send_off[k], static_cast<size_t>(2 * c->send_cnt[k]), NCCL_FLOAT64, c->peer[k], c->comm, c->stream), "ncclSend");
+        }
+        nccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
+        HIPCHK(hipEventRecord(c->done, c->stream));
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return 1;
+    }
+}
+
+int rccl_exchange_wait(void* ctx, void* stream) {
+    tm_rccl_comm* c = static_cast<tm_rccl_comm*>(ctx);
+    if (c->peer.empty()) return 0;
+    return hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->done, 0) == hipSuccess ? 0 : 1;
+}
+
+int rccl_allreduce(void* ctx, double* buf, int32_t n, void* stream) {
+    tm_rccl_comm* c = static_cast<tm_rccl_comm*>(ctx);
+    try {
+        if (c->nranks == 1) return 0;
+        // on the transfer stream too: operations of one communicator stay in one queue
+        hipStream_t s = static_cast<hipStream_t>(stream);
+        HIPCHK(hipEventRecord(c->ready, s));
+        HIPCHK(hipStreamWaitEvent(c->stream, c->ready, 0));
+        nccl_check(g_rccl.AllReduce(buf, buf, static_cast<size_t>(n), NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream), "ncclAllReduce");
+        HIPCHK(hipEventRecord(c->done, c->stream));
+        HIPCHK(hipStreamWaitEvent(s, c->done, 0));
+        return 0;
+    } catch (const std::exception& e) {
+        g_last_error = e.what();
+        return 1;
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int tm_rccl_unique_id(const char* librccl_path, void* id_out) {
+    return guarded([&]() {
+        if (!id_out) throw TmError(TM_E_ARG, "null argument");
+        RcclApi& api = rccl_api(librccl_path);
+        NcclUniqueId id;
+        nccl_check(api.GetUniqueId(&id), "ncclGetUniqueId");
+        std::memcpy(id_out, &id, sizeof(id));
+        return TM_OK;
+    });
+}
+
+int tm_rccl_comm_create(const char* librccl_path, const void* id, int32_t rank, int32_t nranks, tm_rccl_comm** out) {
+    return guarded([&]() {
+        if (!id || !out || nranks < 1 || rank < 0 || rank >= nranks) throw TmError(TM_E_ARG, "bad argument");
+        RcclApi& api = rccl_api(librccl_path);
+        auto c = std::make_unique<tm_rccl_comm>();
+        c->rank = rank;
+        c->nranks = nranks;
+        NcclUniqueId uid;
+        std::memcpy(&uid, id, sizeof(uid));
+        nccl_check(api.CommInitRank(&c->comm, nranks, uid, rank), "ncclCommInitRank");
+        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
+        *out = c.release();
+        return TM_OK;
+    });
+}
+
+void tm_rccl_comm_destroy(tm_rccl_comm* c) {
+    if (!c) return;
+    if (c->stream) (void)hipStreamSynchronize(c->stream);
+    if (c->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(c->comm);
+    if (c->ready) (void)hipEventDestroy(c->ready);
+    if (c->done) (void)hipEventDestroy(c->done);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+int tm_rccl_hooks(tm_rccl_comm* c, const tm_mesh_desc* mesh, const int32_t* owner, tm_comm_hooks* hooks) {
+    return guarded([&]() {
+        if (!c || !mesh || !owner || !hooks) throw TmError(TM_E_ARG, "null argument");
+        const Topology topo = topo_of(mesh);
+        c->owner.assign(owner, owner + topo.nblocks());
+        for (int32_t o : c->owner)
+            if (o < 0 || o >= c->nranks) throw TmError(TM_E_ARG, "owner rank out of range");
+        const LocalPlan lp = build_local_plan(topo, build_rows(topo), c->owner, c->rank, c->nranks);
+        c->peer.assign(lp.peer_rank.begin(), lp.peer_rank.end());
+        c->send_off.assign(lp.send_off.begin(), lp.send_off.end());
+        c->send_cnt.assign(lp.send_cnt.begin(), lp.send_cnt.end());
+        c->recv_off.assign(lp.recv_off.begin(), lp.recv_off.end());
+        c->recv_cnt.assign(lp.recv_cnt.begin(), lp.recv_cnt.end());
+        std::memset(hooks, 0, sizeof(*hooks));
+        hooks->ctx = c;
+        hooks->rank = c->rank;
+        hooks->nranks = c->nranks;
+        hooks->owner = c->owner.data();
+        hooks->exchange = rccl_exchange;
+        hooks->exchange_wait = rccl_exchange_wait;
+        hooks->allreduce_sum = rccl_allreduce;
+        return TM_OK;
+    });
+}
+
+}  // extern "C"

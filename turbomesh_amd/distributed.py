@@ -231,3 +231,53 @@ class TorchHooks(HooksBase):
 
     def allreduce(self, t):
         self._x.allreduce(t)
+
+
+class RcclHooks:
+    """tm_comm_hooks served by the library's own RCCL transport (tm_rccl_*): torch.distributed is used once, to hand
+    rank 0's ncclUniqueId to the other ranks; after that no Python runs inside a sweep (a batch_isend_irecv per exchange
+    costs 50-70 us of host time, tools/ubench/p2p_host_cost.py -- more than half of a two-sweep pass of a 4096^2 block)."""
+
+    def __init__(self, mesh, owner, rank, world, option=None, control=None, group=None, device=None):
+        import os
+
+        import torch
+        import torch.distributed as dist
+
+        self.rank, self.world = rank, world
+        L = _capi.lib()
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        self._path = path.encode() if os.path.exists(path) else None
+        device = device or torch.device("cuda", torch.cuda.current_device())
+        uid = (C.c_ubyte * 128)()
+        if rank == 0:
+            _capi.check(L.tm_rccl_unique_id(self._path, uid))
+        if world > 1:
+            on_gpu = dist.get_backend(group) == "nccl"
+            t = torch.tensor(list(bytes(uid)), dtype=torch.uint8, device=device if on_gpu else "cpu")
+            dist.broadcast(t, src=0, group=group)
+            uid = (C.c_ubyte * 128)(*t.cpu().tolist())
+        self._comm = C.c_void_p()
+        _capi.check(L.tm_rccl_comm_create(self._path, uid, rank, world, C.byref(self._comm)))
+        self._owner = (C.c_int32 * len(owner))(*owner)
+        self._md = _capi.MeshDesc(mesh)
+        self._hooks = _capi.tm_comm_hooks()
+        _capi.check(L.tm_rccl_hooks(self._comm, self._md.ref(), self._owner, C.byref(self._hooks)))
+        self.smoother = smooth.Smoother(mesh, option, control, hooks=self._hooks, stream=torch.cuda.current_stream(device).cuda_stream)
+
+    def iterate(self, iterations):
+        return self.smoother.iterate(iterations)
+
+    def close(self):
+        if getattr(self, "smoother", None) is not None:
+            self.smoother.close()
+            self.smoother = None
+        if getattr(self, "_comm", None):
+            _capi.lib().tm_rccl_comm_destroy(self._comm)
+            self._comm = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
