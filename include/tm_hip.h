@@ -229,6 +229,15 @@ uint64_t tm_smoother_dof(const tm_smoother* s);
 /* Current control function (P,Q) per node, 2*dof doubles (wall_control_function.zig:22-54). */
 int tm_smoother_control_function(tm_smoother* s, double* pq);
 
+/* ------------------------------------------------------------------ export (the step right after the path)
+ * The reference's structured output hands the writer one plane per coordinate with i fastest: plane[j*ni + i] =
+ * block(i,j) (reference src/core/cgns.zig:75-104, called from discrete.zig:197-216 Mesh.write and smooth.zig:396-414);
+ * optionally the control function as planes "P" and "Q" (cgns.zig:106-154).  Both entry points do that de-interleaving
+ * transpose on the device.  tm_export_soa: host block in, host planes out.  tm_smoother_export_soa: planes of an owned
+ * block from the coordinates resident in the handle; p, q may both be NULL (laplace exports zeros). */
+int tm_export_soa(const double* xy /* ni*nj*2 */, uint64_t ni, uint64_t nj, double* x_out /* ni*nj */, double* y_out /* ni*nj */);
+int tm_smoother_export_soa(tm_smoother* s, uint64_t block, double* x, double* y, double* p, double* q);
+
 /* Measurement support (bench.py roofline): when enabled, every K2 `winslow_apply` launch is bracketed by a
  * pair of HIP events recorded on the handle's stream; read returns the summed elapsed milliseconds and the
  * number of launches since the last read (and resets both). */

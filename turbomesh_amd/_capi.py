@@ -103,7 +103,7 @@ EXPORTS = [
     "tm_smoother_workspace_bytes", "tm_smoother_iterate", "tm_smoother_download", "tm_smoother_upload", "tm_smoother_destroy",
     "tm_smoother_exchange_plan", "tm_smoother_apply", "tm_smoother_rhs", "tm_smoother_row_kinds", "tm_smoother_dof",
     "tm_smoother_control_function", "tm_smoother_profile", "tm_smoother_profile_read", "tm_plan_build", "tm_plan_free", "tm_plan_local", "tm_plan_local_free", "tm_dev_tfi_block", "tm_dev_relax_sweep",
-    "tm_dev_relax_partials_needed", "tm_rccl_unique_id", "tm_rccl_comm_create", "tm_rccl_comm_destroy", "tm_rccl_hooks",
+    "tm_dev_relax_partials_needed", "tm_export_soa", "tm_smoother_export_soa", "tm_rccl_unique_id", "tm_rccl_comm_create", "tm_rccl_comm_destroy", "tm_rccl_hooks",
 ]
 
 _lib = None
@@ -145,6 +145,8 @@ def lib():
         L.tm_plan_build.argtypes = [C.POINTER(tm_mesh_desc), C.POINTER(tm_plan_rows)]
         L.tm_plan_free.argtypes = [C.POINTER(tm_plan_rows)]
         L.tm_plan_free.restype = None
+        L.tm_export_soa.argtypes = [_dp, C.c_uint64, C.c_uint64, _dp, _dp]
+        L.tm_smoother_export_soa.argtypes = [C.c_void_p, C.c_uint64, _dp, _dp, _dp, _dp]
         L.tm_rccl_unique_id.argtypes = [C.c_char_p, C.c_void_p]
         L.tm_rccl_comm_create.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         L.tm_rccl_comm_destroy.argtypes = [C.c_void_p]

@@ -275,6 +275,29 @@ int tm_smoother_control_function(tm_smoother* s, double* pq) {
     });
 }
 
+int tm_smoother_export_soa(tm_smoother* s, uint64_t block, double* x, double* y, double* p, double* q) {
+    return guarded([&]() {
+        if (!s || !x || !y || ((p == nullptr) != (q == nullptr))) throw TmError(TM_E_ARG, "null argument (p and q come together)");
+        s->impl.export_soa_host(static_cast<int64_t>(block), x, y, p, q);
+        return TM_OK;
+    });
+}
+
+int tm_export_soa(const double* xy, uint64_t ni, uint64_t nj, double* x_out, double* y_out) {
+    return guarded([&]() {
+        if (!xy || !x_out || !y_out) throw TmError(TM_E_ARG, "null argument");
+        if (ni < 1 || nj < 1 || ni * nj >= (uint64_t{1} << 31)) throw TmError(TM_E_SIZE, "block size out of range");
+        require_gfx950();
+        const size_t n = static_cast<size_t>(ni) * nj;
+        DevBuf in(sizeof(double) * 2 * n), out(sizeof(double) * 2 * n);
+        HIPCHK(hipMemcpy(in.p, xy, sizeof(double) * 2 * n, hipMemcpyHostToDevice));
+        HIPCHK(launch_soa_planes(in.as<double2>(), out.as<double>(), out.as<double>() + n, static_cast<int>(ni), static_cast<int>(nj), nullptr));
+        HIPCHK(hipMemcpy(x_out, out.p, sizeof(double) * n, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(y_out, out.as<double>() + n, sizeof(double) * n, hipMemcpyDeviceToHost));
+        return TM_OK;
+    });
+}
+
 int tm_smoother_profile(tm_smoother* s, int enable) {
     return guarded([&]() {
         if (!s) throw TmError(TM_E_ARG, "null handle");

@@ -149,4 +149,7 @@ struct WhiteArgs {
 };
 hipError_t launch_white(const WhiteArgs& w, int update, hipStream_t stream);
 
+// ---- K8 export: interleaved (i*nj + j) block -> two planes with i fastest (cgns.zig:75-104)
+hipError_t launch_soa_planes(const double2* in, double* plane0, double* plane1, int ni, int nj, hipStream_t stream);
+
 }  // namespace tmh

@@ -810,6 +810,40 @@ hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const doubl
     return hipErrorInvalidValue;
 }
 
+// ------------------------------------------------------------------------------------------
+// K8  soa_planes: the export transpose of cgns.zig:75-104 (and :106-154 for P,Q) -- node (i,j) of the
+//     interleaved block (index i*nj + j) goes to plane element j*ni + i (i fastest), x and y (or P and Q)
+//     into separate planes.  32 x 32 tiles through LDS: reads coalesced along j, writes coalesced along i.
+//     HBM-bound, 32 B/node (16 read + 16 written).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_soa_planes(const double2* __restrict__ in, double* __restrict__ plane0, double* __restrict__ plane1, int ni,
+                                                    int nj) {
+    __shared__ double2 tile[32][33];   // +1: the transposed read walks a column
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;   // 32 x 8
+    const int i0 = blockIdx.y * 32, j0 = blockIdx.x * 32;
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int i = i0 + ty + r, j = j0 + tx;
+        if (i < ni && j < nj) tile[ty + r][tx] = in[static_cast<size_t>(i) * nj + j];
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 32; r += 8) {
+        const int j = j0 + ty + r, i = i0 + tx;
+        if (i < ni && j < nj) {
+            const double2 v = tile[tx][ty + r];
+            const size_t o = static_cast<size_t>(j) * ni + i;
+            plane0[o] = v.x;
+            plane1[o] = v.y;
+        }
+    }
+}
+hipError_t launch_soa_planes(const double2* in, double* plane0, double* plane1, int ni, int nj, hipStream_t st) {
+    const dim3 grid((nj + 31) / 32, (ni + 31) / 32), block(256);
+    hipLaunchKernelGGL(k_soa_planes, grid, block, 0, st, in, plane0, plane1, ni, nj);
+    return hipGetLastError();
+}
+
 // right-hand side of the perimeter rows (interior rows have b = 0)
 __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rhs(EdgeRowsDev e, const double2* __restrict__ xk, const double2* __restrict__ pq,
                                                          double2* __restrict__ rhs_out, int scaled, double* partials) {

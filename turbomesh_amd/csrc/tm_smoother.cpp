@@ -615,4 +615,29 @@ void Smoother::control_function_host(double* pq) {
     sync();
 }
 
+// One owned block as planes (x, y and optionally P, Q), element j*ni + i: what cgns.zig:75-154 hands to cg_coord_write /
+// cg_field_write, transposed on the device.
+void Smoother::export_soa_host(int64_t block, double* x, double* y, double* p, double* q) {
+    const auto it = std::lower_bound(lp.owned_blocks.begin(), lp.owned_blocks.end(), block);
+    if (block < 0 || it == lp.owned_blocks.end() || *it != block) throw TmError(TM_E_ARG, "block is not owned by this rank");
+    const int64_t ls = lp.local_start[it - lp.owned_blocks.begin()];
+    const int bi = static_cast<int>(topo.ni[block]), bj = static_cast<int>(topo.nj[block]);
+    const size_t n = static_cast<size_t>(bi) * bj;
+    double* planes = reinterpret_cast<double*>(U);   // the ping-pong vector is free between iterate() calls: n double2 = two planes
+    HIPCHK(launch_soa_planes(X + ls, planes, planes + n, bi, bj, stream));
+    HIPCHK(hipMemcpyAsync(x, planes, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipMemcpyAsync(y, planes + n, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+    if (p && q) {
+        if (PQ) {   // same scratch, after the copies above in stream order
+            HIPCHK(launch_soa_planes(PQ + ls, planes, planes + n, bi, bj, stream));
+            HIPCHK(hipMemcpyAsync(p, planes, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+            HIPCHK(hipMemcpyAsync(q, planes + n, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
+        } else {   // laplace: the control function is identically zero (wall_control_function.zig:22-54)
+            std::memset(p, 0, sizeof(double) * n);
+            std::memset(q, 0, sizeof(double) * n);
+        }
+    }
+    sync();
+}
+
 }  // namespace tmh

@@ -91,6 +91,7 @@ struct Smoother {
     void apply_host(const double* in_xy, double* out_xy, int scaled);
     void rhs_host(double* rhs_xy);
     void control_function_host(double* pq);
+    void export_soa_host(int64_t block, double* x, double* y, double* p, double* q);
 
     // building blocks
     void exchange(double2* vec);        // start (and, without a split hook, finish) the halo exchange of `vec`

@@ -105,3 +105,9 @@ class Mesh:
     def addBlock(self, name, block):
         self.blocks.append(block)
         self.names.append(name)
+
+    def write(self, filename):
+        """discrete.zig:197-216: structured output, planes transposed on the device (turbomesh_amd/output.py)."""
+        from . import output
+
+        output.write_mesh(self, filename)

@@ -69,6 +69,12 @@ class Smoother:
         _capi.check(_capi.lib().tm_smoother_iterate(self._h, iterations, C.byref(st)))
         return st.as_dict()
 
+    def write(self, filename, with_control_function=True):
+        """smooth.zig:396-414 system.write: the coordinates resident on the device (+ P, Q planes)."""
+        from .. import output
+
+        output.write_smoother(self, filename, with_control_function)
+
     def download(self):
         _capi.check(_capi.lib().tm_smoother_download(self._h, self._md.ref()))
 
