@@ -103,7 +103,11 @@ enum { TM_SOLVER_GMRES = 0, TM_SOLVER_BICGSTAB = 1, TM_SOLVER_UMFPACK = 2, TM_SO
 enum {
     TM_INNER_BICGSTAB = 0,   /* Picard outer iteration (smooth.zig:104-154), each frozen-coefficient system solved by
                                 matrix-free BiCGStab on the row-equilibrated operator D^-1 A (replaces BiCGStab.zig:279-370) */
-    TM_INNER_RELAX = 1       /* every outer iteration is ONE fused Jacobi elliptic sweep X <- X + omega D^-1 (b - A(X) X)   */
+    TM_INNER_RELAX = 1,      /* every outer iteration is ONE fused Jacobi elliptic sweep X <- X + omega D^-1 (b - A(X) X)   */
+    TM_INNER_MG_BICGSTAB = 2 /* TM_INNER_BICGSTAB, right-preconditioned by one geometric-multigrid V(2,2) cycle per block
+                                (damped Jacobi, full weighting, rediscretised Winslow operator on vertex-coarsened levels;
+                                perimeter rows keep the identity).  Same Picard iterates, far fewer inner iterations on
+                                large blocks: what makes "to 1e-8 residual at 4096^2" practical               */
 };
 /* tm_solver_opt.flags */
 enum {

@@ -139,3 +139,17 @@ def test_multi_rank_equals_single_rank(name, builder, owner):
     # both runs solve the same frozen systems to rtol 1e-13 with different reduction orders; each is within 1e-10 RMS of the
     # exact iterate (tests/test_gpu_smooth.py), so they may differ from each other by up to twice that
     assert rms <= 2e-10, (name, rms)
+
+
+def test_multi_rank_multigrid_preconditioner():
+    # the V-cycle is block-local (no communication); the outer BiCGStab's exchanges / all-reduces are the same as without it
+    from turbomesh_amd.smoothing import smooth
+
+    builder = lambda: configs.strip(3, 70, 150, reverse_odd=True)
+    opt = solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-13, max_inner=2000, check_every=1)
+    ref = builder()
+    st = smooth.mesh(ref, 3, opt)
+    assert st["not_converged"] == 0
+    got = _run_ranks(builder, [0, 1, 0], opt, 3)
+    rms = float(np.sqrt(np.mean((mesh_flat(got) - mesh_flat(ref)) ** 2)))
+    assert rms <= 2e-10, rms

@@ -18,7 +18,10 @@ enum ApplyMode : int {
     MODE_DIAG_SUM9 = 5,   // out = plain sum of the 9 neighbours (loads, halo, lane shifts; no coefficients)
     MODE_DIAG_NOSTORE = 6,   // full relax arithmetic, all loads, NO store (result folded into the partial sums)
     MODE_DIAG_NOLOAD = 7,    // full relax arithmetic and stores, rows are NOT re-loaded (window reused)
-    MODE_DIAG_MATH = 8       // full relax arithmetic only: no loads, no stores
+    MODE_DIAG_MATH = 8,      // full relax arithmetic only: no loads, no stores
+    // multigrid (block-local error equation D^-1 A e = f, e = 0 on the perimeter; f arrives through `aux`)
+    MODE_MG_RESID = 9,     // out = f - D^-1 A in
+    MODE_MG_SMOOTH = 10    // out = in + omega * (f - D^-1 A in)        (damped Jacobi)
 };
 // ---- fused partial reductions written per workgroup (x and y components separately)
 enum DotMode : int {
@@ -26,7 +29,8 @@ enum DotMode : int {
     DOT_AUX = 1,    // [aux.out]_x, [aux.out]_y                       (sigma = r_hat . v)
     DOT_IN = 2,     // [in.out]_x, [in.out]_y, [out.out]_x, [out.out]_y   (t.s, t.t)
     DOT_OUT2 = 3,   // [out.out]_x, [out.out]_y                       (||r||^2)
-    DOT_DELTA = 4   // [(out-in)^2]_x, [(out-in)^2]_y                 (relax: sum dx^2, dy^2)
+    DOT_DELTA = 4,  // [(out-in)^2]_x, [(out-in)^2]_y                 (relax: sum dx^2, dy^2)
+    DOT_AUX2 = 5    // [aux.out]_x, [aux.out]_y, [out.out]_x, [out.out]_y (t.s, t.t when the operator acted on a preconditioned vector)
 };
 constexpr int MAX_PARTIALS = 4;
 
@@ -119,7 +123,8 @@ hipError_t launch_p_update(const KrylovScalars* S, const double2* r, double2* p,
 hipError_t launch_s_update(const KrylovScalars* S, const double2* r, const double2* v, double2* s, int64_t n, double* partials,
                            hipStream_t stream);
 // u += alpha p + omega s ; r = s - omega t ; partials: r_hat.r (x,y), r.r (x,y)
-hipError_t launch_xr_update(const KrylovScalars* S, double2* u, const double2* p, const double2* s, const double2* t, double2* r,
+// u += alpha*p_hat + omega*s_hat; r = s - omega*t (p_hat = p, s_hat = s without a preconditioner)
+hipError_t launch_xr_update(const KrylovScalars* S, double2* u, const double2* p_hat, const double2* s_hat, const double2* s, const double2* t, double2* r,
                             const double2* r_hat, int64_t n, double* partials, hipStream_t stream);
 // K7: partials sum (xk-u)^2 (x,y); xk <- u
 hipError_t launch_residual_copyback(double2* xk, const double2* u, int64_t n, double* partials, hipStream_t stream);
@@ -148,6 +153,23 @@ struct WhiteArgs {
     double ds_target, theta_target;
 };
 hipError_t launch_white(const WhiteArgs& w, int update, hipStream_t stream);
+
+// ---- multigrid transfer kernels (one block, one pair of levels).  Coarse node c of a coarsened direction sits on fine node
+// min(2c, n_fine - 1): standard vertex coarsening, with one short last cell when n_fine is even (4096 -> 2049 -> 1025 ...).
+struct MgPair {
+    int nif, njf, nic, njc;
+    int ci, cj;   // direction coarsened between the two levels (1) or kept (0)
+};
+// coarse(ci,cj) = scale * fine(f(ci), f(cj)), every node incl. the perimeter (frozen coordinates: scale 1; control function: P x2
+// where i is coarsened, Q x2 where j is -- a first-derivative coefficient in index space)
+hipError_t launch_mg_inject(const double2* fine, double2* coarse, const MgPair& g, double scale_x, double scale_y, hipStream_t stream);
+// f_c = (s_i s_j)^2 * full weighting (1/4 1/2 1/4 per coarsened direction) of the UNscaled fine residual, divided by the coarse
+// diagonal (from the coarse coordinates X_coarse); interior coarse nodes, perimeter untouched (0)
+hipError_t launch_mg_restrict(const double2* r_fine, const double2* X_coarse, double2* f_coarse, const MgPair& g, hipStream_t stream);
+// e_fine += bilinear interpolation of e_coarse, interior fine nodes
+hipError_t launch_mg_prolong_add(const double2* e_coarse, double2* e_fine, const MgPair& g, hipStream_t stream);
+// out = omega * f on interior nodes, 0 on the perimeter: the first damped-Jacobi sweep from a zero guess
+hipError_t launch_mg_scale(const double2* f, double2* out, int ni, int nj, double omega, hipStream_t stream);
 
 // ---- K8 export: interleaved (i*nj + j) block -> two planes with i fastest (cgns.zig:75-104)
 hipError_t launch_soa_planes(const double2* in, double* plane0, double* plane1, int ni, int nj, hipStream_t stream);

@@ -141,6 +141,11 @@ __device__ __forceinline__ void accumulate(double (&acc)[MAX_PARTIALS], double2 
     if (DOT == DOT_AUX) {
         acc[0] += aux.x * out.x;
         acc[1] += aux.y * out.y;
+    } else if (DOT == DOT_AUX2) {
+        acc[0] += aux.x * out.x;
+        acc[1] += aux.y * out.y;
+        acc[2] += out.x * out.x;
+        acc[3] += out.y * out.y;
     } else if (DOT == DOT_IN) {
         acc[0] += in_self.x * out.x;
         acc[1] += in_self.y * out.y;
@@ -311,7 +316,7 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
                 if (!FIELD) load_row(a.xk, prow, g.xpc[u], g.xph[u]);
                 const size_t cur = static_cast<size_t>(min(ib + u, ni - 2)) * nj + jc;
                 if (HAS_PQ) g.pqv[u] = a.pq[cur];
-                if (DOT == DOT_AUX) g.auxv[u] = a.aux[cur];
+                if (DOT == DOT_AUX || DOT == DOT_AUX2 || MODE == MODE_MG_RESID || MODE == MODE_MG_SMOOTH) g.auxv[u] = a.aux[cur];
             }
         };
         // PRED = false: full wave and full row group -> no exec masking around the arithmetic and the store
@@ -338,6 +343,17 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
                     o.y = Wh[M].y + Wc[M].y + Wh[C].y + Wc[C].y + Wh[P3].y + Wc[P3].y;
                 } else if (MODE == MODE_DIAG_NOSTORE || MODE == MODE_DIAG_NOLOAD || MODE == MODE_DIAG_MATH) {
                     o = winslow_row<MODE_RELAX, HAS_PQ>(Wc[M], We[M], Wc[C], We[C], Wh[C], Wc[P3], We[P3], sub2(Wc[P3], Wc[M]), We[C], P, Q, a.omega, delta);
+                } else if (MODE == MODE_MG_RESID || MODE == MODE_MG_SMOOTH) {   // error equation of a multigrid level: frozen field in xk, rhs in aux
+                    const double2 t = winslow_row<MODE_SCALED, HAS_PQ>(Wc[M], We[M], Wc[C], We[C], Wh[C], Wc[P3], We[P3], sub2(Xc[P3], Xc[M]), Xdet, P, Q, 0.0,
+                                                                       delta);
+                    const double2 res = sub2(g.auxv[u], t);
+                    if (MODE == MODE_MG_RESID) {   // UNscaled residual a_ii (f - D^-1 A e): what the restriction averages (see k_mg_restrict)
+                        const double2 dxi = sub2(Xc[P3], Xc[M]);
+                        const double aii = -0.5 * (fma(dxi.x, dxi.x, dxi.y * dxi.y) + fma(Xdet.x, Xdet.x, Xdet.y * Xdet.y));
+                        o = make_double2(aii * res.x, aii * res.y);
+                    } else {
+                        o = make_double2(fma(a.omega, res.x, Wc[C].x), fma(a.omega, res.y, Wc[C].y));
+                    }
                 } else if (FIELD) {
                     o = winslow_row<MODE, HAS_PQ>(Wc[M], We[M], Wc[C], We[C], Wh[C], Wc[P3], We[P3], sub2(Wc[P3], Wc[M]), We[C], P, Q, a.omega, delta);
                 } else {
@@ -356,7 +372,7 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
                     } else {
                         *dst = o;
                     }
-                    accumulate<DOT>(acc, Wc[C], o, (DOT == DOT_AUX) ? g.auxv[u] : ((DOT == DOT_DELTA) ? delta : o));
+                    accumulate<DOT>(acc, Wc[C], o, (DOT == DOT_AUX || DOT == DOT_AUX2) ? g.auxv[u] : ((DOT == DOT_DELTA) ? delta : o));
                 }
                 if (!FIELD) Xdet = sub2(lane_next(g.xph[u], g.xpc[u]), lane_prev(g.xph[u], g.xpc[u]));   // of the next centre row (= row i+1)
             }
@@ -682,11 +698,17 @@ hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_
     if (mode == MODE_RAW && dot == DOT_NONE) return launch_apply_md<MODE_RAW, DOT_NONE>(a, RI, nSG, nRC, st);
     if (mode == MODE_SCALED && dot == DOT_NONE) return launch_apply_md<MODE_SCALED, DOT_NONE>(a, RI, nSG, nRC, st);
     if (mode == MODE_SCALED && dot == DOT_AUX) return launch_apply_md<MODE_SCALED, DOT_AUX>(a, RI, nSG, nRC, st);
+    if (mode == MODE_SCALED && dot == DOT_AUX2) return launch_apply_md<MODE_SCALED, DOT_AUX2>(a, RI, nSG, nRC, st);
     if (mode == MODE_SCALED && dot == DOT_IN) return launch_apply_md<MODE_SCALED, DOT_IN>(a, RI, nSG, nRC, st);
     if (mode == MODE_RESID && dot == DOT_OUT2) return launch_apply_md<MODE_RESID, DOT_OUT2>(a, RI, nSG, nRC, st);
     if (mode == MODE_RESID && dot == DOT_NONE) return launch_apply_md<MODE_RESID, DOT_NONE>(a, RI, nSG, nRC, st);
     if (mode == MODE_RELAX && dot == DOT_DELTA) return launch_apply_md<MODE_RELAX, DOT_DELTA>(a, RI, nSG, nRC, st);
     if (mode == MODE_RELAX && dot == DOT_NONE) return launch_apply_md<MODE_RELAX, DOT_NONE>(a, RI, nSG, nRC, st);
+    if (mode == MODE_MG_RESID || mode == MODE_MG_SMOOTH) {   // never field mode: the frozen coordinates are a different array
+        const bool smooth = mode == MODE_MG_SMOOTH;
+        if (a.pq) return smooth ? launch_apply_u<MODE_MG_SMOOTH, DOT_NONE, false, true>(a, RI, nSG, nRC, st) : launch_apply_u<MODE_MG_RESID, DOT_NONE, false, true>(a, RI, nSG, nRC, st);
+        return smooth ? launch_apply_u<MODE_MG_SMOOTH, DOT_NONE, false, false>(a, RI, nSG, nRC, st) : launch_apply_u<MODE_MG_RESID, DOT_NONE, false, false>(a, RI, nSG, nRC, st);
+    }
     if (mode == MODE_DIAG_COPY) return launch_apply_md<MODE_DIAG_COPY, DOT_NONE>(a, RI, nSG, nRC, st);
     if (mode == MODE_DIAG_SUM9) return launch_apply_md<MODE_DIAG_SUM9, DOT_NONE>(a, RI, nSG, nRC, st);
     if (mode == MODE_DIAG_NOSTORE) return launch_apply_md<MODE_DIAG_NOSTORE, DOT_NONE>(a, RI, nSG, nRC, st);
@@ -784,7 +806,7 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const d
         o.x = row_out<MODE>(sx, rhs_x, diag_x, w_self.x, om);
         o.y = row_out<MODE>(sy, rhs_y, diag_y, w_self.y, om);
         out[row] = o;
-        accumulate<DOT>(acc, w_self, o, (DOT == DOT_AUX) ? aux[row] : ((DOT == DOT_DELTA) ? make_double2(o.x - w_self.x, o.y - w_self.y) : o));
+        accumulate<DOT>(acc, w_self, o, (DOT == DOT_AUX || DOT == DOT_AUX2) ? aux[row] : ((DOT == DOT_DELTA) ? make_double2(o.x - w_self.x, o.y - w_self.y) : o));
     }
     if (DOT != DOT_NONE) block_partials<EDGE_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
@@ -801,6 +823,7 @@ hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const doubl
     TM_EDGE(MODE_RAW, DOT_NONE)
     TM_EDGE(MODE_SCALED, DOT_NONE)
     TM_EDGE(MODE_SCALED, DOT_AUX)
+    TM_EDGE(MODE_SCALED, DOT_AUX2)
     TM_EDGE(MODE_SCALED, DOT_IN)
     TM_EDGE(MODE_RESID, DOT_OUT2)
     TM_EDGE(MODE_RESID, DOT_NONE)
@@ -808,6 +831,96 @@ hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const doubl
     TM_EDGE(MODE_RELAX, DOT_NONE)
 #undef TM_EDGE
     return hipErrorInvalidValue;
+}
+
+// ------------------------------------------------------------------------------------------
+// Multigrid transfer kernels (N4): one thread per node of the level written, j fastest.  All HBM-bound and small next to
+// the smoothing sweeps (K2 in MODE_MG_*): the fine level dominates, each coarser level has 1/4 of the nodes.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ int mg_fine_of(int c, int coarsened, int nf) { return coarsened ? min(2 * c, nf - 1) : c; }
+
+__global__ __launch_bounds__(256) void k_mg_inject(const double2* __restrict__ fine, double2* __restrict__ coarse, MgPair g, double sx, double sy) {
+    const int cj = blockIdx.x * 256 + threadIdx.x, ci = blockIdx.y;
+    if (cj >= g.njc) return;
+    const double2 v = fine[static_cast<size_t>(mg_fine_of(ci, g.ci, g.nif)) * g.njf + mg_fine_of(cj, g.cj, g.njf)];
+    coarse[static_cast<size_t>(ci) * g.njc + cj] = make_double2(sx * v.x, sy * v.y);
+}
+hipError_t launch_mg_inject(const double2* fine, double2* coarse, const MgPair& g, double sx, double sy, hipStream_t st) {
+    hipLaunchKernelGGL(k_mg_inject, dim3((g.njc + 255) / 256, g.nic), dim3(256), 0, st, fine, coarse, g, sx, sy);
+    return hipGetLastError();
+}
+
+// The levels' equations are row-equilibrated (D^-1 A e = f), and D does not scale uniformly between levels, so the residual
+// travels unscaled: with index spacings s_i, s_j in {1,2} the rediscretised operator satisfies A_c = (s_i s_j)^2 A_f in the
+// smooth limit (every term: g22 d_xixi, g11 d_etaeta, g12 d_xieta), hence f_c = (s_i s_j)^2 R(a_ii^f rho_f) / a_ii^c.
+__global__ __launch_bounds__(256) void k_mg_restrict(const double2* __restrict__ rf, const double2* __restrict__ Xc, double2* __restrict__ fc, MgPair g) {
+    const int cj = blockIdx.x * 256 + threadIdx.x + 1, ci = blockIdx.y + 1;   // interior coarse nodes
+    if (cj > g.njc - 2) return;
+    const int fi = g.ci ? 2 * ci : ci, fj = g.cj ? 2 * cj : cj;   // interior coarse nodes never hit the short last cell's clamp
+    double2 acc = make_double2(0.0, 0.0);
+#pragma unroll
+    for (int di = -1; di <= 1; ++di) {
+        if (!g.ci && di != 0) continue;
+        const double wi = g.ci ? (di == 0 ? 0.5 : 0.25) : 1.0;
+#pragma unroll
+        for (int dj = -1; dj <= 1; ++dj) {
+            if (!g.cj && dj != 0) continue;
+            const double w = wi * (g.cj ? (dj == 0 ? 0.5 : 0.25) : 1.0);
+            const double2 v = rf[static_cast<size_t>(fi + di) * g.njf + (fj + dj)];
+            acc.x = fma(w, v.x, acc.x);
+            acc.y = fma(w, v.y, acc.y);
+        }
+    }
+    const size_t o = static_cast<size_t>(ci) * g.njc + cj;
+    const double2 xp = Xc[o + g.njc], xm = Xc[o - g.njc], xr = Xc[o + 1], xl = Xc[o - 1];
+    const double dxx = xp.x - xm.x, dxy = xp.y - xm.y, dex = xr.x - xl.x, dey = xr.y - xl.y;
+    const double aii = -0.5 * (fma(dxx, dxx, dxy * dxy) + fma(dex, dex, dey * dey));
+    const double k = static_cast<double>((g.ci ? 4 : 1) * (g.cj ? 4 : 1)) / ((aii == 0.0) ? 1.0 : aii);
+    fc[o] = make_double2(k * acc.x, k * acc.y);
+}
+hipError_t launch_mg_restrict(const double2* rf, const double2* Xc, double2* fc, const MgPair& g, hipStream_t st) {
+    if (g.nic < 3 || g.njc < 3) return hipSuccess;
+    hipLaunchKernelGGL(k_mg_restrict, dim3((g.njc - 2 + 255) / 256, g.nic - 2), dim3(256), 0, st, rf, Xc, fc, g);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_mg_prolong_add(const double2* __restrict__ ec, double2* __restrict__ ef, MgPair g) {
+    const int j = blockIdx.x * 256 + threadIdx.x + 1, i = blockIdx.y + 1;   // interior fine nodes
+    if (j > g.njf - 2) return;
+    // per direction: an even fine index (or an uncoarsened direction) coincides with a coarse node, an odd one lies midway
+    int ci0 = i, ci1 = i, cj0 = j, cj1 = j;
+    if (g.ci) {
+        ci0 = i >> 1;
+        ci1 = (i + 1) >> 1;
+    }
+    if (g.cj) {
+        cj0 = j >> 1;
+        cj1 = (j + 1) >> 1;
+    }
+    const double2 a = ec[static_cast<size_t>(ci0) * g.njc + cj0], b = ec[static_cast<size_t>(ci0) * g.njc + cj1];
+    const double2 c = ec[static_cast<size_t>(ci1) * g.njc + cj0], d = ec[static_cast<size_t>(ci1) * g.njc + cj1];
+    double2 e = ef[static_cast<size_t>(i) * g.njf + j];
+    e.x += 0.25 * ((a.x + b.x) + (c.x + d.x));   // coinciding indices just repeat a value: weights 1, 1/2 1/2 or 1/4 x 4
+    e.y += 0.25 * ((a.y + b.y) + (c.y + d.y));
+    ef[static_cast<size_t>(i) * g.njf + j] = e;
+}
+hipError_t launch_mg_prolong_add(const double2* ec, double2* ef, const MgPair& g, hipStream_t st) {
+    if (g.nif < 3 || g.njf < 3) return hipSuccess;
+    hipLaunchKernelGGL(k_mg_prolong_add, dim3((g.njf - 2 + 255) / 256, g.nif - 2), dim3(256), 0, st, ec, ef, g);
+    return hipGetLastError();
+}
+
+__global__ __launch_bounds__(256) void k_mg_scale(const double2* __restrict__ f, double2* __restrict__ out, int ni, int nj, double omega) {
+    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    if (j >= nj) return;
+    const bool interior = i >= 1 && i <= ni - 2 && j >= 1 && j <= nj - 2;
+    const size_t o = static_cast<size_t>(i) * nj + j;
+    const double2 v = interior ? f[o] : make_double2(0.0, 0.0);
+    out[o] = make_double2(omega * v.x, omega * v.y);
+}
+hipError_t launch_mg_scale(const double2* f, double2* out, int ni, int nj, double omega, hipStream_t st) {
+    hipLaunchKernelGGL(k_mg_scale, dim3((nj + 255) / 256, ni), dim3(256), 0, st, f, out, ni, nj, omega);
+    return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1031,19 +1144,18 @@ hipError_t launch_s_update(const KrylovScalars* S, const double2* r, const doubl
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(VEC_BLOCK) void k_xr_update(const KrylovScalars* __restrict__ S, double2* __restrict__ u,
-                                                         const double2* __restrict__ p, const double2* __restrict__ s,
-                                                         const double2* __restrict__ t, double2* __restrict__ r,
+__global__ __launch_bounds__(VEC_BLOCK) void k_xr_update(const KrylovScalars* __restrict__ S, double2* __restrict__ u, const double2* p_hat,
+                                                         const double2* s_hat, const double2* s, const double2* __restrict__ t, double2* r,
                                                          const double2* __restrict__ r_hat, int64_t n, double* partials) {
     const double ax = S->alpha[0], ay = S->alpha[1], ox = S->omega[0], oy = S->omega[1];
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
     for (int64_t i = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * VEC_BLOCK) {
-        const double2 pi = p[i], si = s[i], ti = t[i], rh = r_hat[i];
+        const double2 pi = p_hat[i], sh = s_hat[i], si = s[i], ti = t[i], rh = r_hat[i];
         double2 ui = u[i];
-        ui.x += ax * pi.x;   // BiCGStab.zig:329-331
+        ui.x += ax * pi.x;   // BiCGStab.zig:329-331 (x += alpha * p_hat)
         ui.y += ay * pi.y;
-        ui.x += ox * si.x;   // BiCGStab.zig:352-354
-        ui.y += oy * si.y;
+        ui.x += ox * sh.x;   // BiCGStab.zig:352-354 (x += omega * s_hat)
+        ui.y += oy * sh.y;
         u[i] = ui;
         const double2 ri = make_double2(si.x - ox * ti.x, si.y - oy * ti.y);   // BiCGStab.zig:356-358
         r[i] = ri;
@@ -1054,9 +1166,9 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_xr_update(const KrylovScalars* __
     }
     block_partials<VEC_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
-hipError_t launch_xr_update(const KrylovScalars* S, double2* u, const double2* p, const double2* s, const double2* t, double2* r,
+hipError_t launch_xr_update(const KrylovScalars* S, double2* u, const double2* p_hat, const double2* s_hat, const double2* s, const double2* t, double2* r,
                             const double2* r_hat, int64_t n, double* partials, hipStream_t st) {
-    hipLaunchKernelGGL(k_xr_update, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, S, u, p, s, t, r, r_hat, n, partials);
+    hipLaunchKernelGGL(k_xr_update, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, S, u, p_hat, s_hat, s, t, r, r_hat, n, partials);
     return hipGetLastError();
 }
 

@@ -1,0 +1,161 @@
+#include "tm_multigrid.hpp"
+#include "tm_smoother.hpp"
+
+#include <algorithm>
+#include <cmath>
+
+namespace tmh {
+
+#define HIPCHK(x) hip_check((x), #x)
+
+double BlockMG::aspect_of(const double* xy, int ni, int nj) {
+    if (!xy || ni < 3 || nj < 3) return 1.0;
+    const int si = std::max(1, (ni - 2) / 64), sj = std::max(1, (nj - 2) / 64);   // ~4096 samples
+    double sum = 0.0;
+    long cnt = 0;
+    for (int i = 1; i < ni - 1; i += si)
+        for (int j = 1; j < nj - 1; j += sj) {
+            const double* c = xy + 2 * (static_cast<size_t>(i) * nj + j);
+            const double ax = c[2 * nj] - c[-2 * nj], ay = c[2 * nj + 1] - c[-2 * nj + 1];
+            const double bx = c[2] - c[-2], by = c[3] - c[-1];
+            const double g11 = ax * ax + ay * ay, g22 = bx * bx + by * by;
+            if (g11 > 0.0 && g22 > 0.0) {
+                sum += std::log(g11 / g22);
+                cnt += 1;
+            }
+        }
+    return cnt ? std::exp(sum / static_cast<double>(cnt)) : 1.0;
+}
+
+void BlockMG::build(DeviceArena& arena, int ni, int nj, bool has_pq, double aspect, bool worst_case) {
+    if (ni > 65535 || nj < 3 || ni < 3) throw TmError(TM_E_UNSUPPORTED, "multigrid: block rows must be within [3, 65535]");
+    L.clear();
+    MgLevel l0;
+    l0.ni = ni;
+    l0.nj = nj;
+    L.push_back(l0);
+    if (worst_case) {   // tm_smoother_workspace_bytes: semi-coarsening levels sum to < 1 fine block per array, whatever the order
+        const uint64_t n = static_cast<uint64_t>(ni) * nj + 64 * 256;
+        for (int k = 0; k < (has_pq ? 6 : 5); ++k) (void)arena.alloc_n<double2>(n);
+        return;
+    }
+    double ratio = aspect > 0.0 ? aspect : 1.0;   // g11/g22: > 1 = the j direction is the strongly coupled one
+    while (L.size() < 24) {
+        const MgLevel& f = L.back();
+        MgLevel c;
+        c.ci = f.ni >= 5;
+        c.cj = f.nj >= 5;
+        if (c.ci && c.cj) {
+            if (ratio > 4.0) c.ci = 0;          // coarsen j only: g22 x4
+            else if (ratio < 0.25) c.cj = 0;    // coarsen i only: g11 x4
+        }
+        if (!c.ci && !c.cj) break;
+        if (c.ci && !c.cj) ratio *= 4.0;
+        if (c.cj && !c.ci) ratio *= 0.25;
+        c.ni = c.ci ? f.ni / 2 + 1 : f.ni;
+        c.nj = c.cj ? f.nj / 2 + 1 : f.nj;
+        const uint64_t n = static_cast<uint64_t>(c.ni) * c.nj;
+        c.X = arena.alloc_n<double2>(n);
+        if (has_pq) c.PQ = arena.alloc_n<double2>(n);
+        c.f = arena.alloc_n<double2>(n);
+        c.a = arena.alloc_n<double2>(n);
+        c.b = arena.alloc_n<double2>(n);
+        c.r = arena.alloc_n<double2>(n);
+        for (double2* q : {c.f, c.a, c.b, c.r}) HIPCHK(hipMemset(q, 0, sizeof(double2) * n));   // perimeters stay zero for the lifetime of the handle
+        L.push_back(c);
+    }
+}
+
+MgPair BlockMG::pair(size_t fine) const {
+    const MgLevel &f = L[fine], &c = L[fine + 1];
+    MgPair g;
+    g.nif = f.ni;
+    g.njf = f.nj;
+    g.nic = c.ni;
+    g.njc = c.nj;
+    g.ci = c.ci;
+    g.cj = c.cj;
+    return g;
+}
+
+void BlockMG::set_field(const double2* X0, const double2* PQ0, hipStream_t st) {
+    L[0].X = const_cast<double2*>(X0);
+    L[0].PQ = const_cast<double2*>(PQ0);
+    for (size_t l = 0; l + 1 < L.size(); ++l) {
+        const MgPair g = pair(l);
+        HIPCHK(launch_mg_inject(L[l].X, L[l + 1].X, g, 1.0, 1.0, st));
+        if (PQ0) HIPCHK(launch_mg_inject(L[l].PQ, L[l + 1].PQ, g, g.ci ? 2.0 : 1.0, g.cj ? 2.0 : 1.0, st));
+    }
+}
+
+void BlockMG::smooth(const MgLevel& l, const double2* f, const double2* in, double2* out, hipStream_t st) const {
+    ApplyBlock a;
+    a.in = in;
+    a.xk = l.X;
+    a.pq = l.PQ;
+    a.aux = f;
+    a.out = out;
+    a.ni = l.ni;
+    a.nj = l.nj;
+    a.omega = omega;
+    a.partials = nullptr;
+    HIPCHK(launch_apply_block(a, MODE_MG_SMOOTH, DOT_NONE, st));
+}
+
+void BlockMG::residual(const MgLevel& l, const double2* f, const double2* in, double2* out, hipStream_t st) const {
+    ApplyBlock a;
+    a.in = in;
+    a.xk = l.X;
+    a.pq = l.PQ;
+    a.aux = f;
+    a.out = out;
+    a.ni = l.ni;
+    a.nj = l.nj;
+    a.omega = 0.0;
+    a.partials = nullptr;
+    HIPCHK(launch_apply_block(a, MODE_MG_RESID, DOT_NONE, st));
+}
+
+void BlockMG::vcycle(const double2* f0, double2* z, double2* w0, double2* w1, hipStream_t st) {
+    const size_t nl = L.size();
+    std::vector<double2*> cur(nl, nullptr), oth(nl, nullptr);
+    std::vector<const double2*> rhs(nl, nullptr);
+    // fine level: the last post-sweep must land in z; count the ping-pongs after the initial scaling
+    const int pre_extra = nu_pre > 0 ? nu_pre - 1 : 0;
+    const int flips0 = (nl == 1) ? pre_extra + nu_coarsest : pre_extra + nu_post;
+    cur[0] = (flips0 % 2 == 0) ? z : w0;
+    oth[0] = (flips0 % 2 == 0) ? w0 : z;
+    rhs[0] = f0;
+    L[0].r = w1;
+    for (size_t l = 1; l < nl; ++l) {
+        cur[l] = L[l].a;
+        oth[l] = L[l].b;
+        rhs[l] = L[l].f;
+    }
+    auto sweeps = [&](size_t l, int n) {
+        for (int k = 0; k < n; ++k) {
+            smooth(L[l], rhs[l], cur[l], oth[l], st);
+            std::swap(cur[l], oth[l]);
+        }
+    };
+    // ---- down
+    for (size_t l = 0; l < nl; ++l) {
+        HIPCHK(launch_mg_scale(rhs[l], cur[l], L[l].ni, L[l].nj, nu_pre > 0 ? omega : 0.0, st));   // first sweep from e = 0 (also zeroes the perimeter)
+        if (l == 0 && nu_pre + nu_post > 1) HIPCHK(launch_copy_perimeter(w1, oth[0], L[0].ni, L[0].nj, st));   // the other fine iterate: zero perimeter
+        sweeps(l, pre_extra);
+        if (l + 1 == nl) {
+            sweeps(l, nu_coarsest);
+            break;
+        }
+        residual(L[l], rhs[l], cur[l], L[l].r, st);
+        HIPCHK(launch_mg_restrict(L[l].r, L[l + 1].X, L[l + 1].f, pair(l), st));
+    }
+    // ---- up
+    for (size_t l = nl - 1; l-- > 0;) {
+        HIPCHK(launch_mg_prolong_add(cur[l + 1], cur[l], pair(l), st));
+        sweeps(l, nu_post);
+    }
+    if (cur[0] != z) throw TmError(TM_E_ARG, "internal: multigrid result landed in the scratch block");
+}
+
+}  // namespace tmh

@@ -116,7 +116,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     if (!o) throw TmError(TM_E_ARG, "null solver option");
     if (o->tag != TM_SOLVER_HIP)
         throw TmError(TM_E_UNSUPPORTED, "ExternalSolverNotEnabled: libtm_hip serves only solver tag `hip` (gmres/bicgstab/umfpack/petsc stay on the Zig side)");
-    if (o->inner != TM_INNER_BICGSTAB && o->inner != TM_INNER_RELAX) throw TmError(TM_E_ARG, "unknown inner strategy");
+    if (o->inner != TM_INNER_BICGSTAB && o->inner != TM_INNER_RELAX && o->inner != TM_INNER_MG_BICGSTAB) throw TmError(TM_E_ARG, "unknown inner strategy");
     opt = *o;
     if (!(opt.rtol > 0)) opt.rtol = 1e-12;
     if (!(opt.atol > 0)) opt.atol = 0.0;
@@ -169,7 +169,8 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     auto vec = [&]() { return arena.alloc_n<double2>(static_cast<uint64_t>(n_local)); };
     X = vec();
     U = vec();
-    if (opt.inner == TM_INNER_BICGSTAB) {
+    use_mg = opt.inner == TM_INNER_MG_BICGSTAB;
+    if (opt.inner == TM_INNER_BICGSTAB || use_mg) {
         r = vec();
         r_hat = vec();
         p = vec();
@@ -178,6 +179,19 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         t = vec();
     }
     if (white) PQ = vec();
+    if (use_mg) {
+        p_hat = vec();
+        s_hat = vec();
+        mg_w0 = vec();
+        mg_w1 = vec();
+        mg.resize(lp.owned_blocks.size());
+        for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
+            const int64_t b = lp.owned_blocks[k];
+            const int bi = static_cast<int>(topo.ni[b]), bj = static_cast<int>(topo.nj[b]);
+            const double* xy = (mesh && mesh->blocks) ? mesh->blocks[b].xy : nullptr;
+            mg[k].build(arena, bi, bj, white, BlockMG::aspect_of(xy, bi, bj), measure);
+        }
+    }
     // two sweeps per pass (K2x2): Laplace control function only (White updates P,Q between sweeps), every owned block >= 5 x 5
     fuse_pairs = opt.inner == TM_INNER_RELAX && !white && !(opt.flags & TM_OPT_SINGLE_SWEEP);
     for (int64_t b : lp.owned_blocks) fuse_pairs = fuse_pairs && relax2_supported(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
@@ -272,6 +286,8 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_S), sizeof(KrylovScalars), hipHostMallocDefault));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_red), sizeof(double) * MAX_PARTIALS, hipHostMallocDefault));
     HIPCHK(hipMemsetAsync(S, 0, sizeof(KrylovScalars), stream));
+    for (double2* q : {p_hat, s_hat, mg_w0, mg_w1})
+        if (q) HIPCHK(hipMemsetAsync(q, 0, sizeof(double2) * n_local, stream));
     if (PQ) HIPCHK(hipMemsetAsync(PQ, 0, sizeof(double2) * n_local, stream));
     upload(mesh);
     if (white) white_launch(0);   // ControlFunction.init, wall_control_function.zig:27-42
@@ -402,12 +418,24 @@ void Smoother::white_launch(int update) {
     HIPCHK(launch_white(w, update, stream));
 }
 
+// out = M^-1 in: one V-cycle per owned block on the interior rows, identity on the perimeter rows (tm_multigrid.hpp)
+void Smoother::precondition(const double2* in, double2* out) {
+    for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
+        const int64_t b = lp.owned_blocks[k];
+        const int64_t ls = lp.local_start[k];
+        mg[k].vcycle(in + ls, out + ls, mg_w0 + ls, mg_w1 + ls, stream);
+        HIPCHK(launch_copy_perimeter(in + ls, out + ls, static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), stream));
+    }
+}
+
 // ------------------------------------------------------------------ Picard + BiCGStab
 // One outer iteration: returns 1 if the inner solve did not converge.
 int Smoother::picard_bicgstab(tm_stats& st) {
     if (white && outer_done > 0) white_launch(1);   // system.fill(n): control_function.update for n > 0 (smooth.zig:1107-1110)
     exchange(X);
     exchange_finish();
+    if (use_mg)   // level hierarchy of the newly frozen field
+        for (size_t k = 0; k < lp.owned_blocks.size(); ++k) mg[k].set_field(X + lp.local_start[k], PQ ? PQ + lp.local_start[k] : nullptr, stream);
     // warm start: the solution vector starts from the current coordinates (BiCGStab.zig:136-153; later
     // outer iterations continue from the copied-back solution, which is the same field)
     HIPCHK(hipMemcpyAsync(U, X, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));
@@ -439,14 +467,24 @@ int Smoother::picard_bicgstab(tm_stats& st) {
         bool breakdown = false;
         while (it_total < opt.max_inner) {
             HIPCHK(launch_p_update(S, r, p, v, n_owned, stream));
-            apply(p, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0);
+            if (use_mg) {   // right preconditioning (BiCGStab.zig:314-316, 340-342 with M = one V-cycle)
+                precondition(p, p_hat);
+                apply(p_hat, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0);
+            } else {
+                apply(p, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0);
+            }
             HIPCHK(launch_scalar_update(S, red, STEP_SIGMA, stream));
             HIPCHK(launch_s_update(S, r, v, s, n_owned, partials, stream));
             reduce(nwg_vec);
             HIPCHK(launch_scalar_update(S, red, STEP_SS, stream));
-            apply(s, t, MODE_SCALED, DOT_IN, nullptr, X, 0.0);
+            if (use_mg) {
+                precondition(s, s_hat);
+                apply(s_hat, t, MODE_SCALED, DOT_AUX2, s, X, 0.0);   // t.s and t.t with the UNpreconditioned s
+            } else {
+                apply(s, t, MODE_SCALED, DOT_IN, nullptr, X, 0.0);
+            }
             HIPCHK(launch_scalar_update(S, red, STEP_TSTT, stream));
-            HIPCHK(launch_xr_update(S, U, p, s, t, r, r_hat, n_owned, partials, stream));
+            HIPCHK(launch_xr_update(S, U, use_mg ? p_hat : p, use_mg ? s_hat : s, s, t, r, r_hat, n_owned, partials, stream));
             reduce(nwg_vec);
             HIPCHK(launch_scalar_update(S, red, STEP_RHO, stream));
             st.operator_sweeps += 2;

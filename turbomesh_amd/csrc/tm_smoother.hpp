@@ -2,6 +2,7 @@
 #pragma once
 #include "../../include/tm_hip.h"
 #include "tm_kernels.h"
+#include "tm_multigrid.hpp"
 #include "tm_plan.hpp"
 #include <memory>
 #include <string>
@@ -52,6 +53,11 @@ struct Smoother {
     // vectors, double2[n_local]
     double2 *X = nullptr, *U = nullptr, *r = nullptr, *r_hat = nullptr, *p = nullptr, *v = nullptr, *s = nullptr, *t = nullptr;
     double2 *PQ = nullptr, *tmpA = nullptr, *tmpB = nullptr;
+    // multigrid preconditioner (TM_INNER_MG_BICGSTAB): preconditioned search directions, two scratch vectors, one hierarchy per owned block
+    double2 *p_hat = nullptr, *s_hat = nullptr, *mg_w0 = nullptr, *mg_w1 = nullptr;
+    std::vector<BlockMG> mg;
+    bool use_mg = false;
+    void precondition(const double2* in, double2* out);
     double2* M = nullptr;           // X^(k+1) of a fused pair of relax sweeps (perimeter + first-interior ring only)
     bool fuse_pairs = false;
     // perimeter rows

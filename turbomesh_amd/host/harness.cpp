@@ -107,6 +107,7 @@ int main(int argc, char** argv) {
         const std::size_t iterations = std::strtoull(argv[a++], nullptr, 10);
         smoothing::solver::Option opt;
         if (a < argc && std::strcmp(argv[a], "relax") == 0) opt.inner = TM_INNER_RELAX;
+        if (a < argc && std::strcmp(argv[a], "mg") == 0) opt.inner = TM_INNER_MG_BICGSTAB;
         if (a < argc && (std::strcmp(argv[a], "relax") == 0 || std::strcmp(argv[a], "bicgstab") == 0)) ++a;
         opt.rtol = 1e-13;
         opt.max_inner = 5000;

@@ -32,6 +32,7 @@ class Tag(enum.IntEnum):
 class Inner(enum.IntEnum):
     bicgstab = _capi.TM_INNER_BICGSTAB   # Picard + matrix-free BiCGStab on D^-1 A
     relax = _capi.TM_INNER_RELAX         # one fused Jacobi elliptic sweep per outer iteration
+    mg_bicgstab = _capi.TM_INNER_MG_BICGSTAB   # bicgstab, right-preconditioned by one multigrid V-cycle per block
 
 
 @dataclass
