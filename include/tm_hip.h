@@ -196,6 +196,11 @@ int tm_smoother_create(const tm_mesh_desc* mesh, const tm_solver_opt* opt, const
                        const tm_comm_hooks* hooks /* NULL = single process */, void* stream /* hipStream_t or NULL */,
                        tm_smoother** out);
 int tm_smoother_iterate(tm_smoother* s, uint64_t iterations, tm_stats* stats);
+/* Outer iterations until the scaled nonlinear residual stats->scaled_residual_rms = sqrt(||D^-1 (b - A(X) X)||^2 / (2 dof)) is
+ * <= scaled_residual_tol, at most max_iterations of them (the reference iterates a fixed count from its input file,
+ * smooth.zig:104; it has no stop test).  TM_OK = reached; TM_W_NOT_CONVERGED = max_iterations hit or an inner solve did not
+ * converge.  stats->outer_iterations = iterations actually performed (Picard: solves; relax: sweeps, tested every 32). */
+int tm_smoother_iterate_until(tm_smoother* s, uint64_t max_iterations, double scaled_residual_tol, tm_stats* stats);
 int tm_smoother_download(tm_smoother* s, const tm_mesh_desc* mesh);
 int tm_smoother_upload(tm_smoother* s, const tm_mesh_desc* mesh);
 void tm_smoother_destroy(tm_smoother* s);

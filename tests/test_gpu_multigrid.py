@@ -75,3 +75,23 @@ def test_mg_t106_o4h():
         sm.download()
     assert st["not_converged"] == 0
     assert _rms(mesh_flat(mesh), om.flat()) <= 1e-10
+
+
+def test_iterate_until_residual_tolerance():
+    # residual-based stop of the outer iteration (the reference only has a fixed count): the returned mesh satisfies the bound,
+    # a second call returns at once without touching it, and the relax mode honours the same bound in steps of 32 sweeps
+    mesh = configs.single_block(257, 257, perturb=0.25)
+    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-10)) as sm:
+        reached, st = sm.iterate_until(1e-9, 50)
+        assert reached and 1 <= st["outer_iterations"] <= 12 and st["scaled_residual_rms"] <= 1e-9
+        sm.download()
+        before = mesh_flat(mesh).copy()
+        reached, st2 = sm.iterate_until(1e-9, 50)
+        sm.download()
+        assert reached and st2["outer_iterations"] == 0 and np.array_equal(mesh_flat(mesh), before)
+        reached, st3 = sm.iterate_until(1e-30, 2)     # unreachable: stops at the cap and says so
+        assert not reached and st3["outer_iterations"] == 2
+    small = configs.single_block(33, 33, perturb=0.25)
+    with smooth.Smoother(small, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+        reached, st = sm.iterate_until(1e-6, 100000)
+        assert reached and st["outer_iterations"] % 32 == 0 and st["scaled_residual_rms"] <= 1e-6

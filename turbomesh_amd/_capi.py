@@ -100,7 +100,7 @@ class tm_plan_local_info(C.Structure):
 # every symbol include/tm_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
     "tm_last_error", "tm_abi_version", "tm_tfi_block", "tm_tfi_linear2d", "tm_smooth_mesh", "tm_smoother_create",
-    "tm_smoother_workspace_bytes", "tm_smoother_iterate", "tm_smoother_download", "tm_smoother_upload", "tm_smoother_destroy",
+    "tm_smoother_workspace_bytes", "tm_smoother_iterate", "tm_smoother_iterate_until", "tm_smoother_download", "tm_smoother_upload", "tm_smoother_destroy",
     "tm_smoother_exchange_plan", "tm_smoother_apply", "tm_smoother_rhs", "tm_smoother_row_kinds", "tm_smoother_dof",
     "tm_smoother_control_function", "tm_smoother_profile", "tm_smoother_profile_read", "tm_plan_build", "tm_plan_free", "tm_plan_local", "tm_plan_local_free", "tm_dev_tfi_block", "tm_dev_relax_sweep",
     "tm_dev_relax_partials_needed", "tm_export_soa", "tm_smoother_export_soa", "tm_rccl_unique_id", "tm_rccl_comm_create", "tm_rccl_comm_destroy", "tm_rccl_hooks",
@@ -131,6 +131,7 @@ def lib():
         L.tm_smoother_workspace_bytes.argtypes = [C.POINTER(tm_mesh_desc), C.POINTER(tm_solver_opt), C.POINTER(tm_control_fn),
                                                   C.POINTER(tm_comm_hooks), C.POINTER(C.c_uint64)]
         L.tm_smoother_iterate.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(tm_stats)]
+        L.tm_smoother_iterate_until.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.POINTER(tm_stats)]
         L.tm_smoother_download.argtypes = [C.c_void_p, C.POINTER(tm_mesh_desc)]
         L.tm_smoother_upload.argtypes = [C.c_void_p, C.POINTER(tm_mesh_desc)]
         L.tm_smoother_destroy.argtypes = [C.c_void_p]

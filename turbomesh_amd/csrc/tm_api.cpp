@@ -210,6 +210,16 @@ int tm_smoother_iterate(tm_smoother* s, uint64_t iterations, tm_stats* stats) {
         return st.not_converged ? TM_W_NOT_CONVERGED : TM_OK;
     });
 }
+int tm_smoother_iterate_until(tm_smoother* s, uint64_t max_iterations, double scaled_residual_tol, tm_stats* stats) {
+    return guarded([&]() {
+        if (!s) throw TmError(TM_E_ARG, "null handle");
+        if (!(scaled_residual_tol > 0.0)) throw TmError(TM_E_ARG, "the residual tolerance must be positive");
+        tm_stats st;
+        const bool reached = s->impl.iterate_until(max_iterations, scaled_residual_tol, &st);
+        if (stats) *stats = st;
+        return (reached && !st.not_converged) ? TM_OK : TM_W_NOT_CONVERGED;
+    });
+}
 int tm_smoother_download(tm_smoother* s, const tm_mesh_desc* mesh) {
     return guarded([&]() {
         if (!s) throw TmError(TM_E_ARG, "null handle");

@@ -459,6 +459,7 @@ int Smoother::picard_bicgstab(tm_stats& st) {
             HIPCHK(hipMemcpyAsync(h_S, S, sizeof(KrylovScalars), hipMemcpyDeviceToHost, stream));
             sync();
             st.scaled_residual_rms = std::sqrt((h_S->rr0[0] + h_S->rr0[1]) / (2.0 * static_cast<double>(dof_global)));
+            if (stop_tol > 0.0 && st.scaled_residual_rms <= stop_tol) return 2;   // X already satisfies A(X) X = b to stop_tol: leave it untouched
             if (h_S->done[0] == 1 && h_S->done[1] == 1) {
                 converged = true;
                 break;
@@ -598,6 +599,49 @@ void Smoother::iterate(uint64_t iterations, tm_stats* stats) {
     sync();
     st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (stats) *stats = st;
+}
+
+// Outer iterations until the scaled nonlinear residual sqrt(||D^-1 (b - A(X) X)||^2 / (2 dof)) is <= tol (the reference has no
+// stop test; its iteration count comes from the input file).  Picard modes test the residual every iteration (it
+// is the inner solve's start residual, so the test costs nothing); relax mode every 32 sweeps.
+bool Smoother::iterate_until(uint64_t max_iterations, double tol, tm_stats* stats) {
+    const auto t0 = std::chrono::steady_clock::now();
+    tm_stats st;
+    std::memset(&st, 0, sizeof(st));
+    bool reached = false;
+    if (opt.inner == TM_INNER_RELAX) {
+        while (st.outer_iterations < max_iterations) {
+            const uint64_t n = std::min<uint64_t>(32, max_iterations - st.outer_iterations);
+            relax_sweeps(n, st);
+            st.outer_iterations += n;
+            if (st.scaled_residual_rms <= tol) {
+                reached = true;
+                break;
+            }
+        }
+    } else {
+        stop_tol = tol;
+        try {
+            while (true) {
+                const int rc = picard_bicgstab(st);
+                if (rc == 2) {
+                    reached = true;
+                    break;
+                }
+                st.not_converged += rc;
+                st.outer_iterations += 1;
+                if (st.outer_iterations >= max_iterations) break;
+            }
+        } catch (...) {
+            stop_tol = 0.0;
+            throw;
+        }
+        stop_tol = 0.0;
+    }
+    sync();
+    st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) *stats = st;
+    return reached;
 }
 
 void Smoother::profile_read(double* ms_total, uint64_t* launches) {

@@ -75,6 +75,14 @@ class Smoother:
 
         output.write_smoother(self, filename, with_control_function)
 
+    def iterate_until(self, scaled_residual_tol: float, max_iterations: int = 1000):
+        """Iterate until the scaled nonlinear residual is <= tol.  Returns (reached, stats)."""
+        st = _capi.tm_stats()
+        rc = _capi.lib().tm_smoother_iterate_until(self._h, max_iterations, C.c_double(scaled_residual_tol), C.byref(st))
+        if rc < 0:
+            _capi.check(rc)
+        return rc == 0, st.as_dict()
+
     def download(self):
         _capi.check(_capi.lib().tm_smoother_download(self._h, self._md.ref()))
 
