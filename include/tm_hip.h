@@ -120,7 +120,7 @@ typedef struct tm_solver_opt {
     double rtol;             /* stop the inner solve at ||D^-1(b-Ax)||_2 <= max(atol, rtol*||D^-1 b||_2); 0 -> 1e-12 */
     double atol;             /* 0 -> 0 */
     uint64_t max_inner;      /* BiCGStab iteration cap per Picard solve; 0 -> 1000 (BiCGStab.zig:19) */
-    uint32_t check_every;    /* host convergence poll interval in inner iterations; 0 -> 8 */
+    uint32_t check_every;    /* host convergence poll interval in inner iterations; 0 -> 8 (1 with the multigrid preconditioner) */
     uint32_t flags;          /* TM_OPT_* bits; 0 = defaults */
     double omega;            /* relaxation factor of TM_INNER_RELAX; 0 -> 1.0 */
 } tm_solver_opt;

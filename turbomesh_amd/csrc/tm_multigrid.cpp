@@ -3,6 +3,8 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
+#include <cstdlib>
 
 namespace tmh {
 
@@ -29,6 +31,16 @@ double BlockMG::aspect_of(const double* xy, int ni, int nj) {
 
 void BlockMG::build(DeviceArena& arena, int ni, int nj, bool has_pq, double aspect, bool worst_case) {
     if (ni > 65535 || nj < 3 || ni < 3) throw TmError(TM_E_UNSUPPORTED, "multigrid: block rows must be within [3, 65535]");
+    if (const char* e = std::getenv("TM_MG_CYCLE")) {   // tuning knob: "nu_pre,nu_post,nu_coarsest,omega"
+        int a = nu_pre, b = nu_post, c = nu_coarsest;
+        double w = omega;
+        if (std::sscanf(e, "%d,%d,%d,%lf", &a, &b, &c, &w) >= 2 && a >= 0 && b >= 0 && a + b >= 1 && c >= 0 && w > 0.0 && w < 2.0) {
+            nu_pre = a;
+            nu_post = b;
+            nu_coarsest = c;
+            omega = w;
+        }
+    }
     L.clear();
     MgLevel l0;
     l0.ni = ni;
