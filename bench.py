@@ -236,6 +236,11 @@ def main():
             out["cpu_baseline"] = None
         sys.stdout.flush()
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
+    if hooks_obj is not None:   # communicators go before the process group (their teardown is collective)
+        if hasattr(hooks_obj, "close"):
+            hooks_obj.close()
+        else:
+            hooks_obj.smoother.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -24,6 +24,7 @@ def test_harness_built_and_fails_loudly_without_arguments():
 @pytest.mark.parametrize("args,builder", [
     (["strip", "3", "17", "24", "3", "bicgstab"], lambda: configs.strip(3, 17, 24, tfi=oracle_tfi)),
     (["single", "33", "41", "3", "bicgstab"], lambda: configs.single_block(33, 41, tfi=oracle_tfi)),
+    (["strip", "3", "33", "40", "3", "mg"], lambda: configs.strip(3, 33, 40, tfi=oracle_tfi)),   # multigrid-preconditioned inner solve
 ])
 def test_harness_matches_oracle(tmp_path, args, builder):
     dump = str(tmp_path / "dump.bin")

@@ -1,8 +1,8 @@
 // harness.cpp -- plays the role of the Zig caller (reference src/gui/main.zig:30-56, src/wasm/lib.zig:35-55):
 // build edges -> Block2d.init (TFI on the MI355X) -> Mesh with connections -> smooth.mesh -> log like the reference.
 //
-//   tm_harness strip <nblocks> <ni> <nj> <iterations> [relax|bicgstab] [dump.bin]
-//   tm_harness single <ni> <nj> <iterations> [relax|bicgstab] [dump.bin]
+//   tm_harness strip <nblocks> <ni> <nj> <iterations> [relax|bicgstab|mg] [dump.bin]
+//   tm_harness single <ni> <nj> <iterations> [relax|bicgstab|mg] [dump.bin]
 //
 // The synthetic edges are those of SURVEY.md 8d (config 2 / config 4), identical to turbomesh_amd/configs.py.
 // dump.bin (optional): all block coordinates as raw f64 after smoothing, for the parity test.
@@ -92,7 +92,7 @@ static discrete::Mesh buildSingle(std::size_t ni, std::size_t nj) {
 int main(int argc, char** argv) {
     try {
         if (argc < 5) {
-            std::fprintf(stderr, "usage: %s strip <nblocks> <ni> <nj> <iterations> [relax|bicgstab] [dump.bin]\n       %s single <ni> <nj> <iterations> [relax|bicgstab] [dump.bin]\n", argv[0], argv[0]);
+            std::fprintf(stderr, "usage: %s strip <nblocks> <ni> <nj> <iterations> [relax|bicgstab|mg] [dump.bin]\n       %s single <ni> <nj> <iterations> [relax|bicgstab|mg] [dump.bin]\n", argv[0], argv[0]);
             return 2;
         }
         int a = 2;
@@ -108,7 +108,7 @@ int main(int argc, char** argv) {
         smoothing::solver::Option opt;
         if (a < argc && std::strcmp(argv[a], "relax") == 0) opt.inner = TM_INNER_RELAX;
         if (a < argc && std::strcmp(argv[a], "mg") == 0) opt.inner = TM_INNER_MG_BICGSTAB;
-        if (a < argc && (std::strcmp(argv[a], "relax") == 0 || std::strcmp(argv[a], "bicgstab") == 0)) ++a;
+        if (a < argc && (std::strcmp(argv[a], "relax") == 0 || std::strcmp(argv[a], "bicgstab") == 0 || std::strcmp(argv[a], "mg") == 0)) ++a;
         opt.rtol = 1e-13;
         opt.max_inner = 5000;
         const tm_stats st = smoothing::smooth::mesh(mesh, iterations, opt, smoothing::wall_control_function::Algorithm::laplace());
