@@ -171,7 +171,9 @@ typedef struct tm_smoother tm_smoother;
  * the mesh description handed to create() is the GLOBAL topology, `owner[b]` names the rank
  * that owns block b, only owned blocks need coordinates.  exchange() must fill recv_buf (device)
  * from the peers' send_buf (device) according to the plan returned by tm_smoother_exchange_plan;
- * allreduce_sum() sums n doubles in place (device) over all ranks.  Both are enqueued on `stream`. */
+ * allreduce_sum() sums n doubles in place (device) over all ranks.  Every call names the stream it must be ordered on:
+ * the handle's stream, or -- for the exchanges of relaxation sweep pairs -- a second stream the handle owns, on which the
+ * exchanges and perimeter rows run beside the interior pass. */
 typedef struct tm_comm_hooks {
     void* ctx;
     int32_t rank, nranks;

@@ -21,21 +21,31 @@ class _Shared:
         self.n = n
         self.barrier = threading.Barrier(n, timeout=120)
         self.send = [None] * n
+        self.done = [None] * n
         self.plan = [None] * n
         self.red = [None] * n
         self.tmp = [None] * n
 
 
 class ThreadHooks(HooksBase):
+    """Transport between handles living on one device.  Every hook call arrives with torch's current stream set to the stream
+    the library named (HooksBase._on_stream); handles have their own side streams, so the hand-over is fenced with events:
+    `ready` = my pack kernel has filled my send buffer, `done` = my copies out of the peers' send buffers have run."""
+
     def __init__(self, shared, *a, **kw):
         self.shared = shared
         super().__init__(*a, **kw)
         shared.plan[self.rank] = self.plan
 
-    def exchange(self, send, recv):
+    def _post(self, send, recv):
+        import torch
+
         sh = self.shared
-        sh.send[self.rank] = send
-        sh.barrier.wait()   # every rank has enqueued its pack kernel on the (shared) stream
+        st = torch.cuda.current_stream()
+        ready = torch.cuda.Event()
+        ready.record(st)
+        sh.send[self.rank] = (send, ready)
+        sh.barrier.wait()   # every rank has published its send buffer and its event
         for k, peer in enumerate(self.plan["peer_rank"]):
             ro, rc = 2 * int(self.plan["recv_offset"][k]), 2 * int(self.plan["recv_count"][k])
             pp = sh.plan[int(peer)]
@@ -43,8 +53,25 @@ class ThreadHooks(HooksBase):
             so, sc = 2 * int(pp["send_offset"][idx]), 2 * int(pp["send_count"][idx])
             assert sc == rc
             if rc:
-                recv[ro:ro + rc].copy_(sh.send[int(peer)][so:so + sc])
-        sh.barrier.wait()   # nobody repacks before every peer has enqueued its copies
+                psend, pready = sh.send[int(peer)]
+                st.wait_event(pready)
+                recv[ro:ro + rc].copy_(psend[so:so + sc])
+        done = torch.cuda.Event()
+        done.record(st)
+        sh.done[self.rank] = done
+
+    def _close(self):
+        import torch
+
+        sh = self.shared
+        sh.barrier.wait()   # every rank has enqueued its copies
+        st = torch.cuda.current_stream()
+        for peer in self.plan["peer_rank"]:
+            st.wait_event(sh.done[int(peer)])   # nobody repacks its send buffer before its peers have read it
+
+    def exchange(self, send, recv):
+        self._post(send, recv)
+        self._close()
 
     def allreduce(self, t):
         sh = self.shared
@@ -62,19 +89,10 @@ class SplitThreadHooks(ThreadHooks):
     """Split form: exchange() posts the copies, exchange_wait() closes the phase (the library runs K2 in between)."""
 
     def exchange(self, send, recv):
-        sh = self.shared
-        sh.send[self.rank] = send
-        sh.barrier.wait()
-        for k, peer in enumerate(self.plan["peer_rank"]):
-            ro, rc = 2 * int(self.plan["recv_offset"][k]), 2 * int(self.plan["recv_count"][k])
-            pp = sh.plan[int(peer)]
-            idx = list(pp["peer_rank"]).index(self.rank)
-            so, sc = 2 * int(pp["send_offset"][idx]), 2 * int(pp["send_count"][idx])
-            if rc:
-                recv[ro:ro + rc].copy_(sh.send[int(peer)][so:so + sc])
+        self._post(send, recv)
 
     def exchange_wait(self):
-        self.shared.barrier.wait()
+        self._close()
 
 
 def _run_ranks(builder, owner, option, iterations, rounds=1, hooks_cls=None):

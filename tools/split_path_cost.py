@@ -1,0 +1,33 @@
+#!/usr/bin/env python3
+"""Cost of the multi-rank sweep schedule without a second GPU: rank 0 of a 2-rank strip with a transport that moves nothing
+(ghost rows stay stale, so the coordinates are meaningless -- only the timing is).  Shows what the pack kernels, the
+three-part K2x2 launch and the hook calls add to the single-rank pass."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from turbomesh_amd import distributed as tmd
+from turbomesh_amd.smoothing import solver
+
+class NullHooks(tmd.HooksBase):
+    def exchange(self, send, recv):
+        pass
+    def exchange_wait(self):
+        pass
+    def allreduce(self, t):
+        pass
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+steps = 200
+torch.cuda.set_device(0)
+for world in (2, 3):
+    rank = 1 if world == 3 else 0      # world 3, rank 1: neighbours on both sides
+    mesh = tmd.strip_for_rank(world, rank, n, n)
+    h = NullHooks(mesh, owner=list(range(world)), rank=rank, world=world, option=solver.Option.hip(inner=solver.Inner.relax))
+    h.iterate(20)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    h.iterate(steps)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    print(f"world {world} rank {rank}: {dt / steps * 1e6:.1f} us per sweep ({n * n * steps / dt:.3e} nodes/s) with a null transport", flush=True)
+    h.smoother.close()

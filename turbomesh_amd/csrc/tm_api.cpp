@@ -199,6 +199,12 @@ void tm_smoother_destroy(tm_smoother* s) {
     if (s->impl.h_red) (void)hipHostFree(s->impl.h_red);
     for (hipEvent_t e : s->impl.ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : s->impl.ev_stop) (void)hipEventDestroy(e);
+    if (s->impl.side) {
+        (void)hipStreamSynchronize(s->impl.side);
+        (void)hipEventDestroy(s->impl.ev_to_side);
+        (void)hipEventDestroy(s->impl.ev_to_main);
+        (void)hipStreamDestroy(s->impl.side);
+    }
     delete s;
 }
 int tm_smoother_iterate(tm_smoother* s, uint64_t iterations, tm_stats* stats) {

@@ -65,9 +65,9 @@ bool relax2_supported(int ni, int nj);
 int relax2_rows_per_chunk(int ni, int nj);   // rows per workgroup chosen for this block on this device (fixed at handle creation)
 int relax2_block_nwg(int ni, int nj, int rows_per_chunk);
 // Which workgroups of the K2x2 grid a launch runs.  BORDER = every workgroup with a wave that reads perimeter values of X^(k+1)
-// from `mid` or writes its first-interior ring; INSIDE_A / INSIDE_B = the two halves of the rest, which read nothing but
+// from `mid` or writes its first-interior ring; INSIDE = the rest (INSIDE_A / INSIDE_B: its two halves), which read nothing but
 // interior rows of X^k -- a multi-rank handle runs them while the halo exchanges are in flight.
-enum Relax2Subset { R2_ALL = 0, R2_BORDER = 1, R2_INSIDE_A = 2, R2_INSIDE_B = 3 };
+enum Relax2Subset { R2_ALL = 0, R2_BORDER = 1, R2_INSIDE_A = 2, R2_INSIDE_B = 3, R2_INSIDE = 4 };
 hipError_t launch_relax2_block(const Relax2Block& a, int rows_per_chunk, int dot, int subset, hipStream_t stream);
 void tune_fuse_rows(int rows);
 

@@ -598,7 +598,7 @@ __global__ __launch_bounds__(256) void k_relax2(Relax2Block a, int RI, int nSG, 
 
     if (subset != R2_ALL) {   // workgroup-uniform: this launch runs only part of the tiles (see Relax2Subset)
         const bool wg_inside = (sg * 240 >= 4) && ((sg * 4 + 3) * 60 + 61 <= nj - 3) && (t.i0 >= 4) && (t.i1 + 1 <= ni - 3);
-        const bool mine = (subset == R2_BORDER) ? !wg_inside : (wg_inside && ((subset == R2_INSIDE_A) == (rc < nRC / 2)));
+        const bool mine = (subset == R2_BORDER) ? !wg_inside : (wg_inside && (subset == R2_INSIDE || ((subset == R2_INSIDE_A) == (rc < nRC / 2))));
         if (!mine) return;   // its partial sums are written by the launch that does run it
     }
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};

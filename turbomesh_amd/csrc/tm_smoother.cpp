@@ -332,19 +332,25 @@ void Smoother::download(const tm_mesh_desc* mesh) {
 }
 
 // ------------------------------------------------------------------ building blocks
-void Smoother::exchange(double2* vec) {
+void Smoother::exchange(double2* vec, hipStream_t on) {
     if (!has_hooks || (n_send == 0 && n_ghost == 0)) return;
-    HIPCHK(launch_gather_rows(vec, d_send_ids, n_send, d_send_buf, stream));
-    const int rc = hooks.exchange(hooks.ctx, reinterpret_cast<const double*>(d_send_buf), reinterpret_cast<double*>(vec + n_owned), stream);
+    hipStream_t st = on ? on : stream;
+    HIPCHK(launch_gather_rows(vec, d_send_ids, n_send, d_send_buf, st));
+    const int rc = hooks.exchange(hooks.ctx, reinterpret_cast<const double*>(d_send_buf), reinterpret_cast<double*>(vec + n_owned), st);
     if (rc != 0) throw TmError(TM_E_COMM, "halo exchange hook failed with code " + std::to_string(rc));
     exchange_pending = hooks.exchange_wait != nullptr;
 }
 
-void Smoother::exchange_finish() {
+void Smoother::exchange_finish(hipStream_t on) {
     if (!exchange_pending) return;
     exchange_pending = false;
-    const int rc = hooks.exchange_wait(hooks.ctx, stream);
+    const int rc = hooks.exchange_wait(hooks.ctx, on ? on : stream);
     if (rc != 0) throw TmError(TM_E_COMM, "halo exchange wait hook failed with code " + std::to_string(rc));
+}
+
+void Smoother::fence(hipStream_t from, hipStream_t to, hipEvent_t ev) {
+    HIPCHK(hipEventRecord(ev, from));
+    HIPCHK(hipStreamWaitEvent(to, ev, 0));
 }
 
 void Smoother::reduce(int nwg) {
@@ -523,7 +529,7 @@ int Smoother::picard_bicgstab(tm_stats& st) {
 //   perimeter rows of X^(k+2)  <- perimeter-row kernel on M (perimeter + ring + exchanged ghost rows are all it reads)
 // With several ranks the K2x2 grid is launched in three parts so that both halo exchanges (of X^k, then of X^(k+1)) travel
 // while workgroups that touch neither perimeter nor ring are running.
-void Smoother::relax2_launch(int subset, bool counts) {
+void Smoother::relax2_launch(int subset, bool counts, int dot) {
     for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
         const int64_t b = lp.owned_blocks[k];
         const int64_t ls = lp.local_start[k];
@@ -535,31 +541,85 @@ void Smoother::relax2_launch(int subset, bool counts) {
         a.nj = static_cast<int>(topo.nj[b]);
         a.omega = opt.omega;
         a.partials = partials + static_cast<size_t>(poff2[k]) * MAX_PARTIALS;
-        profiled([&]() { HIPCHK(launch_relax2_block(a, rows2[k], DOT_DELTA, subset, stream)); }, counts);
+        profiled([&]() { HIPCHK(launch_relax2_block(a, rows2[k], dot, subset, stream)); }, counts);
     }
 }
 
-void Smoother::relax_pair() {
-    const bool split = has_hooks && (n_send > 0 || n_ghost > 0);
+// want_partials: only the pass whose displacement norms are read back pays for them (the last one of an iterate() call)
+void Smoother::relax_pair(bool want_partials) {
+    const int dot = want_partials ? DOT_DELTA : DOT_NONE;
     exchange(X);
-    if (split) relax2_launch(R2_INSIDE_A, false);
     exchange_finish();
     HIPCHK(launch_edge_rows(edge, X, X, PQ, nullptr, M, opt.omega, MODE_RELAX, DOT_NONE, partials, stream));
-    relax2_launch(split ? R2_BORDER : R2_ALL, true);
+    relax2_launch(R2_ALL, true, dot);
     exchange(M);
-    if (split) relax2_launch(R2_INSIDE_B, false);
     exchange_finish();
-    HIPCHK(launch_edge_rows(edge, M, M, PQ, nullptr, U, opt.omega, MODE_RELAX, DOT_DELTA, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, stream));
+    HIPCHK(launch_edge_rows(edge, M, M, PQ, nullptr, U, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, stream));
     std::swap(X, U);
+}
+
+// Sweep pairs of a rank that has neighbours: two streams.  The interior pass of a pair (workgroups that touch neither the
+// perimeter nor the first-interior ring: ~88 % of a 4096^2 block) needs nothing but interior rows of its input, so it starts as
+// soon as the previous pair's border workgroups are done -- while, on the side stream, the previous pair's second exchange
+// (X^(k+1) perimeter + ring), its closing perimeter rows, this pair's first exchange (X^(k+2)) and its opening perimeter rows
+// run one after the other.  Only the border workgroups wait for that chain.
+//     main:  I(0)      B(0) | I(1) ................ B(1) | I(2) ...
+//     side:  x E1(0) /      \ x E2(0) x E1(1) ..... /    \ x E2(1) x E1(2) ...          x = gather + halo exchange
+// Buffers: A = complete input, Bf = output, M = perimeter + ring of the intermediate field; A and Bf swap after every pair.
+void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
+    if (!side) {
+        HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        HIPCHK(hipEventCreateWithFlags(&ev_to_side, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_to_main, hipEventDisableTiming));
+    }
+    auto edge_on_side = [&](const double2* in, double2* out, int dot) {
+        HIPCHK(launch_edge_rows(edge, in, in, PQ, nullptr, out, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, side));
+    };
+    auto exchange_on_side = [&](double2* vec) {
+        exchange(vec, side);
+        exchange_finish(side);
+    };
+    // K2x2 parts read X (input) and write U (output) through relax2_launch: keep X/U pointing at the pair in flight
+    int dot = (npairs == 1 && want_partials_last) ? DOT_DELTA : DOT_NONE;
+    fence(stream, side, ev_to_side);   // X is complete on the main stream
+    exchange_on_side(X);
+    edge_on_side(X, M, DOT_NONE);      // E1(0): perimeter rows of the intermediate field
+    relax2_launch(R2_INSIDE, false, dot);
+    fence(side, stream, ev_to_main);
+    relax2_launch(R2_BORDER, true, dot);
+    for (uint64_t k = 0; k < npairs; ++k) {
+        fence(stream, side, ev_to_side);   // the border workgroups of pair k have left the ring of the intermediate field in M
+        exchange_on_side(M);
+        edge_on_side(M, U, dot);           // E2(k): perimeter rows of the pair's output
+        if (k + 1 == npairs) {
+            fence(side, stream, ev_to_main);
+            std::swap(X, U);
+            break;
+        }
+        // pair k+1: input = this pair's output (interior complete on the main stream, perimeter arriving on the side stream)
+        std::swap(X, U);
+        dot = (k + 2 == npairs && want_partials_last) ? DOT_DELTA : DOT_NONE;
+        relax2_launch(R2_INSIDE, false, dot);
+        exchange_on_side(X);
+        edge_on_side(X, M, DOT_NONE);      // E1(k+1)
+        fence(side, stream, ev_to_main);
+        relax2_launch(R2_BORDER, true, dot);
+    }
 }
 
 void Smoother::relax_sweeps(uint64_t n, tm_stats& st) {
     int last_nwg = nwg_apply;
     uint64_t k = 0;
-    for (; fuse_pairs && k + 2 <= n; k += 2) {
-        relax_pair();
-        st.operator_sweeps += 2;
-        outer_done += 2;
+    if (fuse_pairs && n >= 2) {
+        const uint64_t npairs = n / 2;
+        if (has_hooks && (n_send > 0 || n_ghost > 0)) {
+            relax_pairs_pipelined(npairs, n % 2 == 0);
+        } else {
+            for (uint64_t q = 0; q < npairs; ++q) relax_pair(q + 1 == npairs && n % 2 == 0);
+        }
+        k = 2 * npairs;
+        st.operator_sweeps += k;
+        outer_done += k;
         last_nwg = nwg_apply2;
     }
     for (; k < n; ++k) {

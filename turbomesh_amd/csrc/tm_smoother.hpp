@@ -102,8 +102,13 @@ struct Smoother {
     void export_soa_host(int64_t block, double* x, double* y, double* p, double* q);
 
     // building blocks
-    void exchange(double2* vec);        // start (and, without a split hook, finish) the halo exchange of `vec`
-    void exchange_finish();             // split hooks: make the stream wait for the transfer started by exchange()
+    void exchange(double2* vec, hipStream_t on = nullptr);   // start (and, without a split hook, finish) the halo exchange of `vec`; on = the handle's stream unless given
+    void exchange_finish(hipStream_t on = nullptr);          // split hooks: make the stream wait for the transfer started by exchange()
+    // second stream of a multi-rank relax handle: halo exchanges and perimeter rows of a sweep pair run here, beside the interior pass
+    hipStream_t side = nullptr;
+    hipEvent_t ev_to_side = nullptr, ev_to_main = nullptr;
+    void fence(hipStream_t from, hipStream_t to, hipEvent_t ev);
+    void relax_pairs_pipelined(uint64_t npairs, bool want_partials_last);
     bool exchange_pending = false;
     void apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega);
     void reduce(int nwg);   // partials -> red (+ all-reduce)
@@ -114,9 +119,9 @@ struct Smoother {
    private:
     int picard_bicgstab(tm_stats& st);
     void relax_sweeps(uint64_t n, tm_stats& st);
-    void relax_pair();
+    void relax_pair(bool want_partials);
     void profiled(const std::function<void()>& launch, bool counts = true);
-    void relax2_launch(int subset, bool counts);
+    void relax2_launch(int subset, bool counts, int dot);
 };
 
 }  // namespace tmh

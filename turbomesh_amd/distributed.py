@@ -133,6 +133,7 @@ class HooksBase:
         split = type(self).exchange_wait is not HooksBase.exchange_wait   # subclass implements the split form
         self._wait_cb = _capi.EXCHANGE_WAIT_FN(self._on_exchange_wait) if split else _capi.EXCHANGE_WAIT_FN()
         self._views = {}
+        self._stream_ctx = {}
         hooks = _capi.tm_comm_hooks(None, rank, world, self._owner, self._exchange_cb, self._allreduce_cb, self._wait_cb, None, 0)
         opt = (option or _solver.Option.hip()).c_struct()
         from .smoothing import wall_control_function as _wcf
@@ -173,9 +174,20 @@ class HooksBase:
             v = self._views[key] = self.workspace[off:off + ndoubles]
         return v
 
+    def _on_stream(self, stream):
+        """The library names the stream every hook call belongs to (a sweep pair's exchanges run on the handle's side stream,
+        beside the interior pass): make it torch's current stream, so that copies and NCCL work are ordered against it."""
+        key = int(stream or 0)
+        ctx = self._stream_ctx.get(key)
+        if ctx is None:
+            dev = self.workspace.device
+            ctx = self._stream_ctx[key] = self.torch.cuda.ExternalStream(key, device=dev) if key else self.torch.cuda.default_stream(dev)
+        return self.torch.cuda.stream(ctx)
+
     def _on_exchange(self, ctx, send_ptr, recv_ptr, stream):
         try:
-            self.exchange(self._view(send_ptr, 2 * self.n_send) if self.n_send else None, self._view(recv_ptr, 2 * self.n_ghost) if self.n_ghost else None)
+            with self._on_stream(stream):
+                self.exchange(self._view(send_ptr, 2 * self.n_send) if self.n_send else None, self._view(recv_ptr, 2 * self.n_ghost) if self.n_ghost else None)
             return 0
         except BaseException as e:   # never let an exception cross the C boundary
             self._exc = e
@@ -183,7 +195,8 @@ class HooksBase:
 
     def _on_exchange_wait(self, ctx, stream):
         try:
-            self.exchange_wait()
+            with self._on_stream(stream):
+                self.exchange_wait()
             return 0
         except BaseException as e:
             self._exc = e
@@ -191,7 +204,8 @@ class HooksBase:
 
     def _on_allreduce(self, ctx, buf, n, stream):
         try:
-            self.allreduce(self._view(buf, int(n)))
+            with self._on_stream(stream):
+                self.allreduce(self._view(buf, int(n)))
             return 0
         except BaseException as e:
             self._exc = e
