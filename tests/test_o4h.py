@@ -102,3 +102,25 @@ def test_gpu_t106_white_control_function():
         sm.download()
     rms = float(np.sqrt(np.mean((mesh_flat(mesh) - om.flat()) ** 2)))
     assert rms <= 1e-9, (rms, st)   # (P,Q) go through device acos/atan2: looser than the Laplace bar
+
+
+@pytest.mark.gpu
+def test_cli_runs_the_t106_input_with_the_hip_solver(tmp_path):
+    # python -m turbomesh_amd <json> = gui/main.zig:27-56 without the GUI; the file's own solver (gmres) is refused like a
+    # reference build without the external solver, --hip swaps in the device solver
+    import subprocess
+    import sys
+
+    from turbomesh_amd import output
+
+    cfg = os.path.join("examples", "T106", "T106.json")   # like the reference: paths relative to the working directory
+    env = dict(os.environ, PYTHONPATH=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    r = subprocess.run([sys.executable, "-m", "turbomesh_amd", cfg], capture_output=True, text=True, timeout=300, cwd=GOLD, env=env)
+    assert r.returncode != 0 and "ExternalSolverNotEnabled" in r.stderr
+    out = str(tmp_path / "t106.xyz")
+    r = subprocess.run([sys.executable, "-m", "turbomesh_amd", cfg, "--hip", "--iterations", "2", "--output", out], capture_output=True, text=True,
+                       timeout=300, cwd=GOLD, env=env)
+    assert r.returncode == 0, r.stderr
+    blocks = output.read_plot3d(out)
+    assert [(b[0], b[1]) for b in blocks] == [(221, 41), (121, 41), (11, 41), (11, 51), (121, 41), (161, 11), (21, 91), (11, 131)]
+    assert all(np.isfinite(b[2]).all() and np.isfinite(b[3]).all() for b in blocks)

@@ -1,0 +1,48 @@
+"""`python -m turbomesh_amd <config.json>` -- the reference program's batch path (src/gui/main.zig:27-56 without the GUI):
+parse the input file (input.zig:25-41), build the geometry, run the blocking template (TFI of every block on the GPU),
+smooth, write the mesh.
+
+The example inputs name the reference's own solvers ("gmres" + "ilu0"), which stay on the Zig side: like a reference build
+without UMFPACK answers error.ExternalSolverNotEnabled, this program refuses them -- unless --hip replaces the solver entry
+by {"hip": {"inner": "mg_bicgstab"}} (what a user would write into the JSON)."""
+from __future__ import annotations
+
+import argparse
+import logging
+import os
+import sys
+
+from . import input as tm_input
+from .smoothing import smooth, solver
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser(prog="python -m turbomesh_amd", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
+    ap.add_argument("config", help="input file in the reference's JSON schema (examples/T106/T106.json)")
+    ap.add_argument("--hip", nargs="?", const="mg_bicgstab", choices=["bicgstab", "mg_bicgstab", "relax"],
+                    help="use the hip solver with this inner strategy instead of the solver named in the file")
+    ap.add_argument("--iterations", type=int, help="override smoothing.iterations")
+    ap.add_argument("--output", help="override the output file (.xyz / .p3d: multi-block PLOT3D)")
+    args = ap.parse_args(argv)
+    logging.basicConfig(level=logging.INFO, format="%(levelname)s(%(name)s): %(message)s")
+
+    with open(args.config) as f:
+        inp = tm_input.Input.parse(f.read())
+    if args.hip:
+        inp.solver = solver.Option.hip(inner=getattr(solver.Inner, args.hip))
+    if inp.solver.tag != solver.Tag.hip:
+        sys.exit(f"error.ExternalSolverNotEnabled: solver `{inp.solver.tag.name}` is served by the Zig program; "
+                 "use \"solver\": {\"hip\": {}} in the input file or pass --hip")
+    geometry = inp.geometry(os.getcwd())   # profile files are named relative to the working directory, as in the reference
+    mesh = inp.template.run(geometry)                                   # blocking (O4H.zig:67-118) + TFI per block
+    iterations = inp.iterations if args.iterations is None else args.iterations
+    stats = smooth.mesh(mesh, iterations, inp.solver, inp.wall_control_function)
+    out = args.output or inp.output
+    if out:
+        mesh.write(out)
+        logging.getLogger("output").info("wrote %s (%d blocks, %d nodes)", out, len(mesh.blocks), sum(b.points.data.shape[0] * b.points.data.shape[1] for b in mesh.blocks))
+    return stats
+
+
+if __name__ == "__main__":
+    main()
