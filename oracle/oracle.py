@@ -124,6 +124,8 @@ def lib():
         L.orc_mirror_apply_block.argtypes = [C.c_int, C.c_uint64, C.c_uint64, _dp, _dp, _dp, _dp, C.c_double]
         L.orc_time_relax_sweeps.restype = C.c_double
         L.orc_time_relax_sweeps.argtypes = [C.c_uint64, C.c_uint64, _dp, _dp, C.c_uint64, C.c_double]
+        L.orc_time_relax_sweeps_mt.restype = C.c_double
+        L.orc_time_relax_sweeps_mt.argtypes = [C.c_uint64, C.c_uint64, _dp, _dp, C.c_uint64, C.c_double, C.c_uint32]
         _lib = L
     return _lib
 
@@ -448,6 +450,14 @@ def mirror_apply_block(mode, vec, xk, pq=None, omega=1.0, out=None):
         out = np.zeros_like(vec)
     _check(lib().orc_mirror_apply_block(mode, C.c_uint64(vec.shape[0]), C.c_uint64(vec.shape[1]), vp, xp, pqp, out.ctypes.data_as(_dp), C.c_double(omega)))
     return out
+
+
+def time_relax_sweeps_mt(xy, sweeps, threads, omega=1.0):
+    """time_relax_sweeps with the rows of every sweep split over `threads` host threads (same bits)."""
+    assert xy.dtype == np.float64 and xy.flags["C_CONTIGUOUS"]
+    scratch = np.empty_like(xy)
+    return float(lib().orc_time_relax_sweeps_mt(C.c_uint64(xy.shape[0]), C.c_uint64(xy.shape[1]), xy.ctypes.data_as(_dp),
+                                                scratch.ctypes.data_as(_dp), C.c_uint64(sweeps), C.c_double(omega), C.c_uint32(threads)))
 
 
 def time_relax_sweeps(xy, sweeps, omega=1.0):

@@ -11,6 +11,8 @@
 #include <chrono>
 #include <cmath>
 #include <cstring>
+#include <thread>
+#include <vector>
 
 namespace orc {
 
@@ -55,6 +57,16 @@ static inline Vec2d mirror_row(int mode, bool has_pq, Vec2d m_l, Vec2d m_c, Vec2
 }
 
 // interior rows of one block: out(i,j) = row(in; coefficients from xk, pq); perimeter of `out` untouched
+static void mirror_apply_rows(int mode, Index i_begin, Index i_end, Index nj, const Vec2d* in, const Vec2d* xk, const Vec2d* pq, Vec2d* out, Float omega) {
+    for (Index i = i_begin; i < i_end; ++i)
+        for (Index j = 1; j + 1 < nj; ++j) {
+            const Index p = i * nj + j;
+            const Float P = pq ? pq[p].data[0] : 0.0, Q = pq ? pq[p].data[1] : 0.0;
+            out[p] = mirror_row(mode, pq != nullptr, in[p - nj - 1], in[p - nj], in[p - nj + 1], in[p - 1], in[p], in[p + 1], in[p + nj - 1],
+                                in[p + nj], in[p + nj + 1], xk[p - nj], xk[p + nj], xk[p - 1], xk[p + 1], P, Q, omega);
+        }
+}
+
 void mirror_apply_block(int mode, Index ni, Index nj, const Vec2d* in, const Vec2d* xk, const Vec2d* pq, Vec2d* out, Float omega) {
     for (Index i = 1; i + 1 < ni; ++i)
         for (Index j = 1; j + 1 < nj; ++j) {
@@ -86,6 +98,30 @@ double orc_time_relax_sweeps(uint64_t ni, uint64_t nj, double* xy, double* scrat
     const auto t0 = clk::now();
     for (uint64_t s = 0; s < sweeps; ++s) {
         orc::mirror_apply_block(orc::MIRROR_RELAX, ni, nj, a, a, nullptr, b, omega);
+        std::swap(a, b);
+    }
+    const auto t1 = clk::now();
+    if (sweeps % 2 == 1) std::memcpy(xy, scratch, sizeof(orc::Vec2d) * ni * nj);
+    return std::chrono::duration<double>(t1 - t0).count();
+}
+
+// The same sweeps with the rows of every sweep split over `threads` host threads (NOT the reference's behaviour -- it is
+// single-threaded; reported beside the 1-thread figure as "what the host could do").  Same arithmetic, same bits.
+double orc_time_relax_sweeps_mt(uint64_t ni, uint64_t nj, double* xy, double* scratch, uint64_t sweeps, double omega, uint32_t threads) {
+    using clk = std::chrono::steady_clock;
+    orc::Vec2d* a = reinterpret_cast<orc::Vec2d*>(xy);
+    orc::Vec2d* b = reinterpret_cast<orc::Vec2d*>(scratch);
+    std::memcpy(b, a, sizeof(orc::Vec2d) * ni * nj);
+    const uint32_t T = threads ? threads : 1;
+    const auto t0 = clk::now();
+    for (uint64_t s = 0; s < sweeps; ++s) {
+        std::vector<std::thread> pool;
+        const uint64_t rows = ni - 2;
+        for (uint32_t t = 0; t < T; ++t) {
+            const uint64_t r0 = 1 + rows * t / T, r1 = 1 + rows * (t + 1) / T;
+            pool.emplace_back([=]() { orc::mirror_apply_rows(orc::MIRROR_RELAX, r0, r1, nj, a, a, nullptr, b, omega); });
+        }
+        for (auto& th : pool) th.join();
         std::swap(a, b);
     }
     const auto t1 = clk::now();

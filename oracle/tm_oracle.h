@@ -152,6 +152,8 @@ int orc_mirror_apply_block(int mode, uint64_t ni, uint64_t nj, const double* in,
                            double* out, double omega);
 /* `sweeps` matrix-free Jacobi elliptic sweeps of a fixed-boundary block in the device operation order. */
 double orc_time_relax_sweeps(uint64_t ni, uint64_t nj, double* xy, double* scratch, uint64_t sweeps, double omega);
+/* the same with every sweep's rows split over `threads` host threads (not the reference's behaviour: it is single-threaded) */
+double orc_time_relax_sweeps_mt(uint64_t ni, uint64_t nj, double* xy, double* scratch, uint64_t sweeps, double omega, uint32_t threads);
 
 #ifdef __cplusplus
 }

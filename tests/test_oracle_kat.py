@@ -195,3 +195,13 @@ def test_reference_faithful_solvers_reach_their_own_tolerance():
     om = OracleMesh(m)
     oracle.smooth_mesh(om, 3, solver=oracle.SOLVER_DIRECT)
     assert np.abs(om.flat() - exact.flat()).max() < 1e-13   # banded LU == scipy splu: the exact Picard iterate
+
+
+def test_threaded_relax_sweeps_equal_single_thread():
+    # bench.py's cpu_baseline reports the mirror sweep on 1 thread (faithful) and on all threads: same arithmetic, same bits
+    i, j = np.meshgrid(np.linspace(0, 1, 70), np.linspace(0, 1, 131), indexing="ij")
+    xy = np.stack([i + 0.01 * np.sin(7 * j), j + 0.01 * np.cos(5 * i)], axis=2).copy()
+    a, b = xy.copy(), xy.copy()
+    oracle.time_relax_sweeps(a, 5)
+    oracle.time_relax_sweeps_mt(b, 5, 6)
+    assert np.array_equal(a, b) and not np.array_equal(a, xy)
