@@ -54,7 +54,7 @@ def cpu_baseline(n, budget_s=15.0):
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = max(1, min(threads, 64))
     t1m = oracle.time_relax_sweeps_mt(xy, 2, threads)
-    sweeps_m = max(2, min(2048, int(0.5 * budget_s / max(t1m / 2, 1e-4))))
+    sweeps_m = max(2, min(2048, int(6.0 / max(t1m / 2, 1e-4))))   # ~6 s
     tm = oracle.time_relax_sweeps_mt(xy, sweeps_m, threads)
     return {
         "all_threads": {"value": e_n * e_n * sweeps_m / tm, "unit": "nodes/s", "cores": threads,
