@@ -38,7 +38,7 @@ def test_fused_pairs_equal_single_sweeps_on_every_topology(name, sweeps):
 
 
 # block shapes around the tiling edges: 60-column strips (4 per workgroup = 240), 64-row chunks, the 5 x 5 minimum
-SHAPES = [(5, 5), (5, 64), (6, 61), (7, 62), (61, 63), (63, 121), (66, 122), (67, 181), (130, 241), (131, 242), (129, 243), (200, 483)]
+SHAPES = [(5, 5), (5, 64), (6, 61), (7, 62), (61, 63), (63, 121), (66, 122), (67, 181), (130, 241), (131, 242), (129, 243), (200, 483), (24, 20011), (20011, 24)]
 
 
 @pytest.mark.parametrize("ni,nj", SHAPES)

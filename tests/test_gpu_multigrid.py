@@ -35,7 +35,7 @@ def test_mg_picard_iterates_match_exact_oracle(name):
             assert st["last_residual"] == pytest.approx(hist[k], rel=1e-6, abs=1e-30)
 
 
-@pytest.mark.parametrize("ni,nj", [(129, 129), (130, 200), (64, 257), (5, 300), (200, 4)])
+@pytest.mark.parametrize("ni,nj", [(129, 129), (130, 200), (64, 257), (5, 300), (200, 4), (70001, 9)])
 def test_mg_block_shapes_and_iteration_counts(ni, nj):
     # odd / even sizes (an even size coarsens with one short last cell), strong anisotropy in the index space, a direction too
     # short to coarsen: same iterate as the diagonal solver, never more inner iterations
@@ -47,9 +47,12 @@ def test_mg_block_shapes_and_iteration_counts(ni, nj):
     with smooth.Smoother(b, solver.Option.hip(rtol=1e-13, max_inner=20000, check_every=1)) as sm:
         st_d = sm.iterate(2)
         sm.download()
-    assert st_mg["not_converged"] == 0 and st_d["not_converged"] == 0
-    assert _rms(mesh_flat(a), mesh_flat(b)) <= 2e-10
+    assert st_mg["not_converged"] == 0
     assert st_mg["inner_iterations"] <= st_d["inner_iterations"]
+    if st_d["not_converged"]:   # (70001, 9): cells 1000x longer than wide -- the diagonal alone gives up at 20000 iterations
+        assert ni > 65535 and np.all(np.isfinite(mesh_flat(a)))
+        return
+    assert _rms(mesh_flat(a), mesh_flat(b)) <= 2e-10
     if min(ni, nj) >= 64:
         assert st_mg["inner_iterations"] <= 30, st_mg            # mesh-independent: a handful per Picard solve
         assert st_d["inner_iterations"] >= 5 * st_mg["inner_iterations"]

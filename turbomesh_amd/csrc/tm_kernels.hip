@@ -840,13 +840,15 @@ hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const doubl
 __device__ __forceinline__ int mg_fine_of(int c, int coarsened, int nf) { return coarsened ? min(2 * c, nf - 1) : c; }
 
 __global__ __launch_bounds__(256) void k_mg_inject(const double2* __restrict__ fine, double2* __restrict__ coarse, MgPair g, double sx, double sy) {
-    const int cj = blockIdx.x * 256 + threadIdx.x, ci = blockIdx.y;
+    const int cj = blockIdx.x * 256 + threadIdx.x;
     if (cj >= g.njc) return;
-    const double2 v = fine[static_cast<size_t>(mg_fine_of(ci, g.ci, g.nif)) * g.njf + mg_fine_of(cj, g.cj, g.njf)];
-    coarse[static_cast<size_t>(ci) * g.njc + cj] = make_double2(sx * v.x, sy * v.y);
+    for (int ci = blockIdx.y; ci < g.nic; ci += gridDim.y) {   // gridDim.y is capped at 65535
+        const double2 v = fine[static_cast<size_t>(mg_fine_of(ci, g.ci, g.nif)) * g.njf + mg_fine_of(cj, g.cj, g.njf)];
+        coarse[static_cast<size_t>(ci) * g.njc + cj] = make_double2(sx * v.x, sy * v.y);
+    }
 }
 hipError_t launch_mg_inject(const double2* fine, double2* coarse, const MgPair& g, double sx, double sy, hipStream_t st) {
-    hipLaunchKernelGGL(k_mg_inject, dim3((g.njc + 255) / 256, g.nic), dim3(256), 0, st, fine, coarse, g, sx, sy);
+    hipLaunchKernelGGL(k_mg_inject, dim3((g.njc + 255) / 256, std::min(g.nic, 65535)), dim3(256), 0, st, fine, coarse, g, sx, sy);
     return hipGetLastError();
 }
 
@@ -854,8 +856,9 @@ hipError_t launch_mg_inject(const double2* fine, double2* coarse, const MgPair& 
 // travels unscaled: with index spacings s_i, s_j in {1,2} the rediscretised operator satisfies A_c = (s_i s_j)^2 A_f in the
 // smooth limit (every term: g22 d_xixi, g11 d_etaeta, g12 d_xieta), hence f_c = (s_i s_j)^2 R(a_ii^f rho_f) / a_ii^c.
 __global__ __launch_bounds__(256) void k_mg_restrict(const double2* __restrict__ rf, const double2* __restrict__ Xc, double2* __restrict__ fc, MgPair g) {
-    const int cj = blockIdx.x * 256 + threadIdx.x + 1, ci = blockIdx.y + 1;   // interior coarse nodes
+    const int cj = blockIdx.x * 256 + threadIdx.x + 1;   // interior coarse nodes
     if (cj > g.njc - 2) return;
+    for (int ci = blockIdx.y + 1; ci <= g.nic - 2; ci += gridDim.y) {
     const int fi = g.ci ? 2 * ci : ci, fj = g.cj ? 2 * cj : cj;   // interior coarse nodes never hit the short last cell's clamp
     double2 acc = make_double2(0.0, 0.0);
 #pragma unroll
@@ -877,16 +880,18 @@ __global__ __launch_bounds__(256) void k_mg_restrict(const double2* __restrict__
     const double aii = -0.5 * (fma(dxx, dxx, dxy * dxy) + fma(dex, dex, dey * dey));
     const double k = static_cast<double>((g.ci ? 4 : 1) * (g.cj ? 4 : 1)) / ((aii == 0.0) ? 1.0 : aii);
     fc[o] = make_double2(k * acc.x, k * acc.y);
+    }
 }
 hipError_t launch_mg_restrict(const double2* rf, const double2* Xc, double2* fc, const MgPair& g, hipStream_t st) {
     if (g.nic < 3 || g.njc < 3) return hipSuccess;
-    hipLaunchKernelGGL(k_mg_restrict, dim3((g.njc - 2 + 255) / 256, g.nic - 2), dim3(256), 0, st, rf, Xc, fc, g);
+    hipLaunchKernelGGL(k_mg_restrict, dim3((g.njc - 2 + 255) / 256, std::min(g.nic - 2, 65535)), dim3(256), 0, st, rf, Xc, fc, g);
     return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void k_mg_prolong_add(const double2* __restrict__ ec, double2* __restrict__ ef, MgPair g) {
-    const int j = blockIdx.x * 256 + threadIdx.x + 1, i = blockIdx.y + 1;   // interior fine nodes
+    const int j = blockIdx.x * 256 + threadIdx.x + 1;   // interior fine nodes
     if (j > g.njf - 2) return;
+    for (int i = blockIdx.y + 1; i <= g.nif - 2; i += gridDim.y) {
     // per direction: an even fine index (or an uncoarsened direction) coincides with a coarse node, an odd one lies midway
     int ci0 = i, ci1 = i, cj0 = j, cj1 = j;
     if (g.ci) {
@@ -903,23 +908,26 @@ __global__ __launch_bounds__(256) void k_mg_prolong_add(const double2* __restric
     e.x += 0.25 * ((a.x + b.x) + (c.x + d.x));   // coinciding indices just repeat a value: weights 1, 1/2 1/2 or 1/4 x 4
     e.y += 0.25 * ((a.y + b.y) + (c.y + d.y));
     ef[static_cast<size_t>(i) * g.njf + j] = e;
+    }
 }
 hipError_t launch_mg_prolong_add(const double2* ec, double2* ef, const MgPair& g, hipStream_t st) {
     if (g.nif < 3 || g.njf < 3) return hipSuccess;
-    hipLaunchKernelGGL(k_mg_prolong_add, dim3((g.njf - 2 + 255) / 256, g.nif - 2), dim3(256), 0, st, ec, ef, g);
+    hipLaunchKernelGGL(k_mg_prolong_add, dim3((g.njf - 2 + 255) / 256, std::min(g.nif - 2, 65535)), dim3(256), 0, st, ec, ef, g);
     return hipGetLastError();
 }
 
 __global__ __launch_bounds__(256) void k_mg_scale(const double2* __restrict__ f, double2* __restrict__ out, int ni, int nj, double omega) {
-    const int j = blockIdx.x * 256 + threadIdx.x, i = blockIdx.y;
+    const int j = blockIdx.x * 256 + threadIdx.x;
     if (j >= nj) return;
-    const bool interior = i >= 1 && i <= ni - 2 && j >= 1 && j <= nj - 2;
-    const size_t o = static_cast<size_t>(i) * nj + j;
-    const double2 v = interior ? f[o] : make_double2(0.0, 0.0);
-    out[o] = make_double2(omega * v.x, omega * v.y);
+    for (int i = blockIdx.y; i < ni; i += gridDim.y) {
+        const bool interior = i >= 1 && i <= ni - 2 && j >= 1 && j <= nj - 2;
+        const size_t o = static_cast<size_t>(i) * nj + j;
+        const double2 v = interior ? f[o] : make_double2(0.0, 0.0);
+        out[o] = make_double2(omega * v.x, omega * v.y);
+    }
 }
 hipError_t launch_mg_scale(const double2* f, double2* out, int ni, int nj, double omega, hipStream_t st) {
-    hipLaunchKernelGGL(k_mg_scale, dim3((nj + 255) / 256, ni), dim3(256), 0, st, f, out, ni, nj, omega);
+    hipLaunchKernelGGL(k_mg_scale, dim3((nj + 255) / 256, std::min(ni, 65535)), dim3(256), 0, st, f, out, ni, nj, omega);
     return hipGetLastError();
 }
 

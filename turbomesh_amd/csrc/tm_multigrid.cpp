@@ -30,7 +30,7 @@ double BlockMG::aspect_of(const double* xy, int ni, int nj) {
 }
 
 void BlockMG::build(DeviceArena& arena, int ni, int nj, bool has_pq, double aspect, bool worst_case) {
-    if (ni > 65535 || nj < 3 || ni < 3) throw TmError(TM_E_UNSUPPORTED, "multigrid: block rows must be within [3, 65535]");
+    if (nj < 3 || ni < 3) throw TmError(TM_E_UNSUPPORTED, "multigrid: a block needs at least 3 x 3 nodes");
     if (const char* e = std::getenv("TM_MG_CYCLE")) {   // tuning knob: "nu_pre,nu_post,nu_coarsest,omega"
         int a = nu_pre, b = nu_post, c = nu_coarsest;
         double w = omega;
