@@ -166,7 +166,9 @@ int tm_rccl_comm_create(const char* librccl_path, const void* id, int32_t rank, 
         NcclUniqueId uid;
         std::memcpy(&uid, id, sizeof(uid));
         nccl_check(api.CommInitRank(&c->comm, nranks, uid, rank), "ncclCommInitRank");
-        HIPCHK(hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking));
+        int least = 0, greatest = 0;   // transfers are tiny and latency-critical
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));
         HIPCHK(hipEventCreateWithFlags(&c->ready, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&c->done, hipEventDisableTiming));
         *out = c.release();

@@ -568,7 +568,9 @@ void Smoother::relax_pair(bool want_partials) {
 // Buffers: A = complete input, Bf = output, M = perimeter + ring of the intermediate field; A and Bf swap after every pair.
 void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
     if (!side) {
-        HIPCHK(hipStreamCreateWithFlags(&side, hipStreamNonBlocking));
+        int least = 0, greatest = 0;   // the side chain is short and latency-critical: let its kernels overtake queued interior workgroups
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest));
         HIPCHK(hipEventCreateWithFlags(&ev_to_side, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_to_main, hipEventDisableTiming));
     }
