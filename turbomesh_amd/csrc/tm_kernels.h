@@ -48,6 +48,15 @@ struct ApplyBlock {
 int apply_block_nwg(int ni, int nj);
 void tune_apply(int rows_per_chunk, int unroll, int pipe, int nt);   // <=0 (pipe, nt: <0) keeps the current value
 hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_t stream);
+// several blocks of one rank in one launch (per group of APPLY_BATCH_MAX); block k's partial sums go to blocks[k].partials
+constexpr int APPLY_BATCH_MAX = 8;
+struct ApplyBatch {
+    ApplyBlock b[APPLY_BATCH_MAX];
+    int RI[APPLY_BATCH_MAX], nSG[APPLY_BATCH_MAX], nRC[APPLY_BATCH_MAX];
+    int start[APPLY_BATCH_MAX];   // first workgroup of block k (unused entries: the grid size)
+    int n;
+};
+hipError_t launch_apply_blocks(const ApplyBlock* blocks, int n, int mode, int dot, hipStream_t stream);
 
 // ---- K2x2: TWO fused Jacobi sweeps of one block in one pass (field mode, Laplace).  `in` = X^k (all rows),
 // `mid` = X^(k+1): its perimeter rows must already hold the perimeter-row kernel's result for X^k; the kernel

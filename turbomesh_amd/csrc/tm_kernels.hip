@@ -247,15 +247,15 @@ static int g_nt = 1;
 
 typedef double d2v __attribute__((ext_vector_type(2)));
 
+// One workgroup's tile of one block; `bid` = the workgroup's index within that block's tiles (also its partial-sum slot).
 template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool NT>
-__global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, int nRC) {
+__device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG, int nRC, int bid) {
     static_assert(U % 3 == 0, "the 3-row window rotates by renaming: the row group must be a multiple of 3");
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     // XCD-aware tile order: physical workgroup b runs on XCD b%8; give each XCD a contiguous
     // range of logical tiles (speed only, any placement is correct).
     const int total = nSG * nRC;
-    const int bid = blockIdx.x;
     const int q = total >> 3, rem = total & 7, xcd = bid & 7, k = bid >> 3;
     const int logical = (xcd < rem) ? xcd * (q + 1) + k : rem * (q + 1) + (xcd - rem) * q + k;
     const int rc = logical / nSG;
@@ -394,6 +394,22 @@ __global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, in
     }
     if ((MODE == MODE_DIAG_NOSTORE || MODE == MODE_DIAG_MATH) && acc[0] + acc[1] == 123.456) a.out[0] = make_double2(acc[0], acc[1]);   // keep the arithmetic live
     if (DOT != DOT_NONE) block_partials<256>(acc, a.partials + static_cast<size_t>(bid) * MAX_PARTIALS);
+}
+
+template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool NT>
+__global__ __launch_bounds__(256) void k_apply(ApplyBlock a, int RI, int nSG, int nRC) {
+    apply_tile<MODE, DOT, FIELD, HAS_PQ, U, NT>(a, RI, nSG, nRC, blockIdx.x);
+}
+
+// The same for up to APPLY_BATCH_MAX blocks in ONE launch: a multi-block mesh on one GPU (the O4H examples: 8 small blocks) is
+// launch-bound, not bandwidth-bound.  start[k] = first workgroup of block k.
+template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool NT>
+__global__ __launch_bounds__(256) void k_apply_batch(ApplyBatch B) {
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < APPLY_BATCH_MAX; ++q)
+        if (q < B.n && static_cast<int>(blockIdx.x) >= B.start[q]) k = q;
+    apply_tile<MODE, DOT, FIELD, HAS_PQ, U, NT>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], static_cast<int>(blockIdx.x) - B.start[k]);
 }
 
 
@@ -687,6 +703,60 @@ static hipError_t launch_apply_md(const ApplyBlock& a, int RI, int nSG, int nRC,
     if (field) return launch_apply_u<MODE, DOT, true, false>(a, RI, nSG, nRC, st);
     if (pq) return launch_apply_u<MODE, DOT, false, true>(a, RI, nSG, nRC, st);
     return launch_apply_u<MODE, DOT, false, false>(a, RI, nSG, nRC, st);
+}
+
+template <int MODE, int DOT, bool FIELD, bool HAS_PQ>
+static hipError_t launch_batch_u(const ApplyBatch& B, int total, hipStream_t st) {
+    const dim3 grid(total), block(256);
+    if (g_nt) hipLaunchKernelGGL((k_apply_batch<MODE, DOT, FIELD, HAS_PQ, 3, true>), grid, block, 0, st, B);
+    else hipLaunchKernelGGL((k_apply_batch<MODE, DOT, FIELD, HAS_PQ, 3, false>), grid, block, 0, st, B);
+    return hipGetLastError();
+}
+template <int MODE, int DOT>
+static hipError_t launch_batch_md(const ApplyBatch& B, int total, bool field, bool pq, hipStream_t st) {
+    if (field && pq) return launch_batch_u<MODE, DOT, true, true>(B, total, st);
+    if (field) return launch_batch_u<MODE, DOT, true, false>(B, total, st);
+    if (pq) return launch_batch_u<MODE, DOT, false, true>(B, total, st);
+    return launch_batch_u<MODE, DOT, false, false>(B, total, st);
+}
+
+// Several blocks, one launch per group of APPLY_BATCH_MAX.  All blocks share mode / dot and the field-mode / control-function
+// flavour; each block's `partials` already points at its own slots.  Modes: the ones the Krylov and relaxation loops use.
+hipError_t launch_apply_blocks(const ApplyBlock* blocks, int n, int mode, int dot, hipStream_t st) {
+    if (n == 1) return launch_apply_block(blocks[0], mode, dot, st);
+    for (int first = 0; first < n; first += APPLY_BATCH_MAX) {
+        ApplyBatch B;
+        B.n = 0;
+        int total = 0;
+        bool field = true, pq = true;
+        for (int k = first; k < n && B.n < APPLY_BATCH_MAX; ++k) {
+            const ApplyBlock& a = blocks[k];
+            if (a.ni < 3 || a.nj < 3) continue;   // no interior rows
+            const int q = B.n++;
+            B.b[q] = a;
+            B.RI[q] = rows_per_chunk(a.ni);
+            B.nSG[q] = (a.nj + 255) / 256;
+            B.nRC[q] = (a.ni - 2 + B.RI[q] - 1) / B.RI[q];
+            B.start[q] = total;
+            total += B.nSG[q] * B.nRC[q];
+            field = field && (a.in == a.xk);
+            pq = pq && (a.pq != nullptr);
+        }
+        if (B.n == 0) continue;
+        for (int q = B.n; q < APPLY_BATCH_MAX; ++q) B.start[q] = total;
+        hipError_t e = hipErrorInvalidValue;
+        if (mode == MODE_SCALED && dot == DOT_NONE) e = launch_batch_md<MODE_SCALED, DOT_NONE>(B, total, field, pq, st);
+        else if (mode == MODE_RAW && dot == DOT_NONE) e = launch_batch_md<MODE_RAW, DOT_NONE>(B, total, field, pq, st);
+        else if (mode == MODE_SCALED && dot == DOT_AUX) e = launch_batch_md<MODE_SCALED, DOT_AUX>(B, total, field, pq, st);
+        else if (mode == MODE_SCALED && dot == DOT_AUX2) e = launch_batch_md<MODE_SCALED, DOT_AUX2>(B, total, field, pq, st);
+        else if (mode == MODE_SCALED && dot == DOT_IN) e = launch_batch_md<MODE_SCALED, DOT_IN>(B, total, field, pq, st);
+        else if (mode == MODE_RESID && dot == DOT_OUT2) e = launch_batch_md<MODE_RESID, DOT_OUT2>(B, total, field, pq, st);
+        else if (mode == MODE_RESID && dot == DOT_NONE) e = launch_batch_md<MODE_RESID, DOT_NONE>(B, total, field, pq, st);
+        else if (mode == MODE_RELAX && dot == DOT_DELTA) e = launch_batch_md<MODE_RELAX, DOT_DELTA>(B, total, field, pq, st);
+        else if (mode == MODE_RELAX && dot == DOT_NONE) e = launch_batch_md<MODE_RELAX, DOT_NONE>(B, total, field, pq, st);
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 
 hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_t st) {

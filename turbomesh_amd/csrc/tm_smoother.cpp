@@ -383,10 +383,11 @@ void Smoother::profiled(const std::function<void()>& launch, bool counts) {
 
 void Smoother::apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega) {
     exchange(const_cast<double2*>(in));
+    std::vector<ApplyBlock> blocks(lp.owned_blocks.size());
     for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
         const int64_t b = lp.owned_blocks[k];
         const int64_t ls = lp.local_start[k];
-        ApplyBlock a;
+        ApplyBlock& a = blocks[k];
         a.in = in + ls;
         a.xk = xk + ls;
         a.pq = PQ ? PQ + ls : nullptr;
@@ -396,8 +397,9 @@ void Smoother::apply(const double2* in, double2* out, int mode, int dot, const d
         a.nj = static_cast<int>(topo.nj[b]);
         a.omega = omega;
         a.partials = partials + static_cast<size_t>(poff[k]) * MAX_PARTIALS;
-        profiled([&]() { HIPCHK(launch_apply_block(a, mode, dot, stream)); });
     }
+    // all owned blocks in one launch (groups of APPLY_BATCH_MAX): small multi-block meshes are launch-bound
+    profiled([&]() { HIPCHK(launch_apply_blocks(blocks.data(), static_cast<int>(blocks.size()), mode, dot, stream)); });
     exchange_finish();   // K2 above read owned rows only; the perimeter rows below read the ghost rows
     HIPCHK(launch_edge_rows(edge, in, xk, PQ, aux, out, omega, mode, dot, partials + static_cast<size_t>(poff_edge) * MAX_PARTIALS, stream));
     if (dot != DOT_NONE && dot != DOT_DELTA) reduce(nwg_apply);   // relax sweeps leave the per-workgroup partials; summed when read
