@@ -78,6 +78,12 @@ int relax2_block_nwg(int ni, int nj, int rows_per_chunk);
 // interior rows of X^k -- a multi-rank handle runs them while the halo exchanges are in flight.
 enum Relax2Subset { R2_ALL = 0, R2_BORDER = 1, R2_INSIDE_A = 2, R2_INSIDE_B = 3, R2_INSIDE = 4 };
 hipError_t launch_relax2_block(const Relax2Block& a, int rows_per_chunk, int dot, int subset, hipStream_t stream);
+struct Relax2Batch {
+    Relax2Block b[8];
+    int RI[8], nSG[8], nRC[8], start[8];
+    int n;
+};
+hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, int subset, hipStream_t stream);
 void tune_fuse_rows(int rows);
 
 // ---- K4/K5 perimeter rows (device SoA, built on the host by tm_plan)

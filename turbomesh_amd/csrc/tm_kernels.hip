@@ -593,12 +593,11 @@ __device__ __forceinline__ void relax2_strip_inside(const Relax2Block& a, const 
 }
 
 template <int DOT, int U, bool NT, bool W1>
-__global__ __launch_bounds__(256) void k_relax2(Relax2Block a, int RI, int nSG, int nRC, int subset) {
+__device__ __forceinline__ void relax2_tile(const Relax2Block& a, int RI, int nSG, int nRC, int subset, int bid) {
     static_assert(U % 3 == 0, "windows rotate by renaming");
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int total = nSG * nRC;
-    const int bid = blockIdx.x;
     const int q8 = total >> 3, rem = total & 7, xcd = bid & 7, k8 = bid >> 3;
     const int logical = (xcd < rem) ? xcd * (q8 + 1) + k8 : rem * (q8 + 1) + (xcd - rem) * q8 + k8;
     const int rc = logical / nSG;
@@ -625,6 +624,21 @@ __global__ __launch_bounds__(256) void k_relax2(Relax2Block a, int RI, int nSG, 
         else relax2_strip_edge<DOT, U, NT, W1>(a, t, acc);
     }
     if (DOT != DOT_NONE) block_partials<256>(acc, a.partials + static_cast<size_t>(bid) * MAX_PARTIALS);
+}
+
+template <int DOT, int U, bool NT, bool W1>
+__global__ __launch_bounds__(256) void k_relax2(Relax2Block a, int RI, int nSG, int nRC, int subset) {
+    relax2_tile<DOT, U, NT, W1>(a, RI, nSG, nRC, subset, blockIdx.x);
+}
+
+// several blocks of a rank in one launch (see k_apply_batch)
+template <int DOT, int U, bool NT, bool W1>
+__global__ __launch_bounds__(256) void k_relax2_batch(Relax2Batch B, int subset) {
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < APPLY_BATCH_MAX; ++q)
+        if (q < B.n && static_cast<int>(blockIdx.x) >= B.start[q]) k = q;
+    relax2_tile<DOT, U, NT, W1>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], subset, static_cast<int>(blockIdx.x) - B.start[k]);
 }
 
 static int g_fuse_rows = 0;   // 0 = choose per block (relax2_rows_per_chunk); > 0 = forced (tm_tune_fuse)
@@ -666,6 +680,37 @@ hipError_t launch_relax2_block(const Relax2Block& a, int RI, int dot, int subset
         else hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, true, false>), grid, block, 0, st, a, RI, nSG, nRC, subset);
     }
     return hipGetLastError();
+}
+hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, int subset, hipStream_t st) {
+    if (n == 1) return launch_relax2_block(blocks[0], rows_per_chunk[0], dot, subset, st);
+    for (int first = 0; first < n; first += APPLY_BATCH_MAX) {
+        Relax2Batch B;
+        B.n = 0;
+        int total = 0;
+        bool w1 = true;
+        for (int k = first; k < n && B.n < APPLY_BATCH_MAX; ++k) {
+            const int q = B.n++;
+            B.b[q] = blocks[k];
+            B.RI[q] = rows_per_chunk[k];
+            B.nSG[q] = ((blocks[k].nj - 1 + 59) / 60 + 3) / 4;
+            B.nRC[q] = (blocks[k].ni - 2 + B.RI[q] - 1) / B.RI[q];
+            B.start[q] = total;
+            total += B.nSG[q] * B.nRC[q];
+            w1 = w1 && blocks[k].omega == 1.0;
+        }
+        for (int q = B.n; q < APPLY_BATCH_MAX; ++q) B.start[q] = total;
+        const dim3 grid(total), block(256);
+        if (dot == DOT_DELTA) {
+            if (w1) hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, true, true>), grid, block, 0, st, B, subset);
+            else hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, true, false>), grid, block, 0, st, B, subset);
+        } else {
+            if (w1) hipLaunchKernelGGL((k_relax2_batch<DOT_NONE, R2_U, true, true>), grid, block, 0, st, B, subset);
+            else hipLaunchKernelGGL((k_relax2_batch<DOT_NONE, R2_U, true, false>), grid, block, 0, st, B, subset);
+        }
+        const hipError_t e = hipGetLastError();
+        if (e != hipSuccess) return e;
+    }
+    return hipSuccess;
 }
 void tune_fuse_rows(int rows) { g_fuse_rows = rows > 0 ? rows : 0; }
 

@@ -532,10 +532,11 @@ int Smoother::picard_bicgstab(tm_stats& st) {
 // With several ranks the K2x2 grid is launched in three parts so that both halo exchanges (of X^k, then of X^(k+1)) travel
 // while workgroups that touch neither perimeter nor ring are running.
 void Smoother::relax2_launch(int subset, bool counts, int dot) {
+    std::vector<Relax2Block> blocks(lp.owned_blocks.size());
     for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
         const int64_t b = lp.owned_blocks[k];
         const int64_t ls = lp.local_start[k];
-        Relax2Block a;
+        Relax2Block& a = blocks[k];
         a.in = X + ls;
         a.mid = M + ls;
         a.out = U + ls;
@@ -543,8 +544,8 @@ void Smoother::relax2_launch(int subset, bool counts, int dot) {
         a.nj = static_cast<int>(topo.nj[b]);
         a.omega = opt.omega;
         a.partials = partials + static_cast<size_t>(poff2[k]) * MAX_PARTIALS;
-        profiled([&]() { HIPCHK(launch_relax2_block(a, rows2[k], dot, subset, stream)); }, counts);
     }
+    profiled([&]() { HIPCHK(launch_relax2_blocks(blocks.data(), rows2.data(), static_cast<int>(blocks.size()), dot, subset, stream)); }, counts);
 }
 
 // want_partials: only the pass whose displacement norms are read back pays for them (the last one of an iterate() call)
