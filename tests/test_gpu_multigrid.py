@@ -98,3 +98,18 @@ def test_iterate_until_residual_tolerance():
     with smooth.Smoother(small, solver.Option.hip(inner=solver.Inner.relax)) as sm:
         reached, st = sm.iterate_until(1e-6, 100000)
         assert reached and st["outer_iterations"] % 32 == 0 and st["scaled_residual_rms"] <= 1e-6
+
+
+@pytest.mark.parametrize("name", ["single_perturbed_33", "strip3_reversed", "channel_periodic_fixed"])
+def test_converged_coordinates_match_cpu(name):
+    # BASELINE target: CONVERGED coordinates within 1e-10 RMS of the CPU path.  CPU: the oracle's exact-solve Picard iteration
+    # run to its fixed point; GPU: iterate_until on the scaled nonlinear residual with the multigrid-preconditioned solver.
+    mesh = TOPOLOGIES[name]()
+    om = OracleMesh(mesh)
+    hist, _ = oracle.picard_exact(om, 40)
+    assert hist[-1] <= 1e-40 or hist[-1] <= 1e-24 * max(hist[0], 1e-300)   # (sum dx^2 + sum dy^2)^2 of the last CPU iteration: converged
+    with smooth.Smoother(mesh, solver.Option.hip(**MG)) as sm:
+        reached, st = sm.iterate_until(1e-13, 60)
+        sm.download()
+    assert reached, st
+    assert _rms(mesh_flat(mesh), om.flat()) <= 1e-10
