@@ -132,6 +132,8 @@ int vec_nwg(int64_t n);
 enum ScalarStep : int { STEP_INIT = 0, STEP_SIGMA = 1, STEP_SS = 2, STEP_TSTT = 3, STEP_RHO = 4, STEP_TOL = 5 };
 // STEP_TOL: red[0..1] = ||D^-1 b||^2 -> tol2 = max(atol, rtol*||D^-1 b||)^2
 hipError_t launch_scalar_update(KrylovScalars* S, const double* red, int step, hipStream_t stream, double rtol = 0.0, double atol = 0.0);
+hipError_t launch_finalize_scalar(const double* partials, int nwg, double* red, KrylovScalars* S, int step, hipStream_t stream, double rtol = 0.0,
+                                  double atol = 0.0);
 // p = r + beta (p - omega v)
 hipError_t launch_p_update(const KrylovScalars* S, const double2* r, double2* p, const double2* v, int64_t n, hipStream_t stream);
 // s = r - alpha v ; partials: ||s||^2 (x,y)

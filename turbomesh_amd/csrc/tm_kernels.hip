@@ -1167,9 +1167,7 @@ int vec_nwg(int64_t n) {
     return static_cast<int>(g);
 }
 
-__global__ void k_scalar_update(KrylovScalars* S, const double* __restrict__ red, int step, double rtol, double atol) {
-    const int c = threadIdx.x;
-    if (c >= 2) return;
+__device__ __forceinline__ void scalar_update_body(KrylovScalars* S, const double* red, int step, double rtol, double atol, int c) {
     const double tiny = 1e-290;
     if (step == STEP_TOL) {
         const double tol = fmax(atol, rtol * sqrt(red[c]));
@@ -1228,6 +1226,35 @@ __global__ void k_scalar_update(KrylovScalars* S, const double* __restrict__ red
         }
         if (c == 0) S->iters += 1;
     }
+}
+__global__ void k_scalar_update(KrylovScalars* S, const double* __restrict__ red, int step, double rtol, double atol) {
+    if (threadIdx.x < 2) scalar_update_body(S, red, step, rtol, atol, threadIdx.x);
+}
+// finalize + scalar update in one launch (single-process handles: nothing has to be all-reduced in between)
+__global__ __launch_bounds__(256) void k_finalize_scalar(const double* __restrict__ partials, int nwg, double* __restrict__ red, KrylovScalars* S, int step,
+                                                         double rtol, double atol) {
+    __shared__ double sh[256][MAX_PARTIALS];
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    for (int i = threadIdx.x; i < nwg; i += 256) {
+#pragma unroll
+        for (int k = 0; k < MAX_PARTIALS; ++k) acc[k] += partials[static_cast<size_t>(i) * MAX_PARTIALS + k];
+    }
+#pragma unroll
+    for (int k = 0; k < MAX_PARTIALS; ++k) sh[threadIdx.x][k] = acc[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {   // same tree as k_finalize: identical sums
+        if (threadIdx.x < off) {
+#pragma unroll
+            for (int k = 0; k < MAX_PARTIALS; ++k) sh[threadIdx.x][k] += sh[threadIdx.x + off][k];
+        }
+        __syncthreads();
+    }
+    if (threadIdx.x < MAX_PARTIALS) red[threadIdx.x] = sh[0][threadIdx.x];
+    if (threadIdx.x < 2) scalar_update_body(S, &sh[0][0], step, rtol, atol, threadIdx.x);
+}
+hipError_t launch_finalize_scalar(const double* partials, int nwg, double* red, KrylovScalars* S, int step, hipStream_t st, double rtol, double atol) {
+    hipLaunchKernelGGL(k_finalize_scalar, dim3(1), dim3(256), 0, st, partials, nwg, red, S, step, rtol, atol);
+    return hipGetLastError();
 }
 hipError_t launch_scalar_update(KrylovScalars* S, const double* red, int step, hipStream_t st, double rtol, double atol) {
     hipLaunchKernelGGL(k_scalar_update, dim3(1), dim3(64), 0, st, S, red, step, rtol, atol);

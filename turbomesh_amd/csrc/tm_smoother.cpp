@@ -361,6 +361,15 @@ void Smoother::reduce(int nwg) {
     }
 }
 
+void Smoother::reduce_update(int nwg, int step, double rtol, double atol) {
+    if (has_hooks) {   // the sums of all ranks are needed before the scalars can move
+        reduce(nwg);
+        HIPCHK(launch_scalar_update(S, red, step, stream, rtol, atol));
+        return;
+    }
+    HIPCHK(launch_finalize_scalar(partials, nwg, red, S, step, stream, rtol, atol));
+}
+
 // runs `launch`; with profiling on, bracketed by a hipEvent pair on the handle's stream
 void Smoother::profiled(const std::function<void()>& launch, bool counts) {
     if (!profile) {
@@ -381,7 +390,7 @@ void Smoother::profiled(const std::function<void()>& launch, bool counts) {
     if (counts) prof_launches += 1;
 }
 
-void Smoother::apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega) {
+void Smoother::apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega, int step) {
     exchange(const_cast<double2*>(in));
     std::vector<ApplyBlock> blocks(lp.owned_blocks.size());
     for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
@@ -402,7 +411,10 @@ void Smoother::apply(const double2* in, double2* out, int mode, int dot, const d
     profiled([&]() { HIPCHK(launch_apply_blocks(blocks.data(), static_cast<int>(blocks.size()), mode, dot, stream)); });
     exchange_finish();   // K2 above read owned rows only; the perimeter rows below read the ghost rows
     HIPCHK(launch_edge_rows(edge, in, xk, PQ, aux, out, omega, mode, dot, partials + static_cast<size_t>(poff_edge) * MAX_PARTIALS, stream));
-    if (dot != DOT_NONE && dot != DOT_DELTA) reduce(nwg_apply);   // relax sweeps leave the per-workgroup partials; summed when read
+    if (dot != DOT_NONE && dot != DOT_DELTA) {   // relax sweeps leave the per-workgroup partials; summed when read
+        if (step >= 0) reduce_update(nwg_apply, step);
+        else reduce(nwg_apply);
+    }
 }
 
 void Smoother::white_launch(int update) {
@@ -449,17 +461,15 @@ int Smoother::picard_bicgstab(tm_stats& st) {
     HIPCHK(hipMemcpyAsync(U, X, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));
     // tolerance from ||D^-1 b||
     HIPCHK(launch_edge_rhs(edge, X, PQ, nullptr, 1, partials, stream));
-    reduce(edge_rows_nwg(edge.nrows));
-    HIPCHK(launch_scalar_update(S, red, STEP_TOL, stream, opt.rtol, opt.atol));
+    reduce_update(edge_rows_nwg(edge.nrows), STEP_TOL, opt.rtol, opt.atol);
 
     int restarts = 0;
     uint64_t it_total = 0;
     bool converged = false;
     while (true) {
         // r = D^-1 (b - A U) ; r_hat = r ; p = v = 0
-        apply(U, r, MODE_RESID, DOT_OUT2, nullptr, X, 0.0);
+        apply(U, r, MODE_RESID, DOT_OUT2, nullptr, X, 0.0, STEP_INIT);
         st.operator_sweeps += 1;
-        HIPCHK(launch_scalar_update(S, red, STEP_INIT, stream));
         HIPCHK(hipMemcpyAsync(r_hat, r, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));
         HIPCHK(hipMemsetAsync(p, 0, sizeof(double2) * n_local, stream));
         HIPCHK(hipMemsetAsync(v, 0, sizeof(double2) * n_local, stream));
@@ -478,24 +488,20 @@ int Smoother::picard_bicgstab(tm_stats& st) {
             HIPCHK(launch_p_update(S, r, p, v, n_owned, stream));
             if (use_mg) {   // right preconditioning (BiCGStab.zig:314-316, 340-342 with M = one V-cycle)
                 precondition(p, p_hat);
-                apply(p_hat, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0);
+                apply(p_hat, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0, STEP_SIGMA);
             } else {
-                apply(p, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0);
+                apply(p, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0, STEP_SIGMA);
             }
-            HIPCHK(launch_scalar_update(S, red, STEP_SIGMA, stream));
             HIPCHK(launch_s_update(S, r, v, s, n_owned, partials, stream));
-            reduce(nwg_vec);
-            HIPCHK(launch_scalar_update(S, red, STEP_SS, stream));
+            reduce_update(nwg_vec, STEP_SS);
             if (use_mg) {
                 precondition(s, s_hat);
-                apply(s_hat, t, MODE_SCALED, DOT_AUX2, s, X, 0.0);   // t.s and t.t with the UNpreconditioned s
+                apply(s_hat, t, MODE_SCALED, DOT_AUX2, s, X, 0.0, STEP_TSTT);   // t.s and t.t with the UNpreconditioned s
             } else {
-                apply(s, t, MODE_SCALED, DOT_IN, nullptr, X, 0.0);
+                apply(s, t, MODE_SCALED, DOT_IN, nullptr, X, 0.0, STEP_TSTT);
             }
-            HIPCHK(launch_scalar_update(S, red, STEP_TSTT, stream));
             HIPCHK(launch_xr_update(S, U, use_mg ? p_hat : p, use_mg ? s_hat : s, s, t, r, r_hat, n_owned, partials, stream));
-            reduce(nwg_vec);
-            HIPCHK(launch_scalar_update(S, red, STEP_RHO, stream));
+            reduce_update(nwg_vec, STEP_RHO);
             st.operator_sweeps += 2;
             it_total += 1;
             if (it_total % opt.check_every == 0 || it_total == opt.max_inner) {

@@ -110,8 +110,10 @@ struct Smoother {
     void fence(hipStream_t from, hipStream_t to, hipEvent_t ev);
     void relax_pairs_pipelined(uint64_t npairs, bool want_partials_last);
     bool exchange_pending = false;
-    void apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega);
+    // step >= 0: the Krylov scalar update that consumes the fused dot products follows the reduction (one launch without hooks)
+    void apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega, int step = -1);
     void reduce(int nwg);   // partials -> red (+ all-reduce)
+    void reduce_update(int nwg, int step, double rtol = 0.0, double atol = 0.0);   // reduce + Krylov scalar update
     void white_launch(int update);
     void sync();
     void ensure_tmp();
