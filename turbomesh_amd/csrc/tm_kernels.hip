@@ -241,8 +241,8 @@ __device__ __forceinline__ double2 add2(double2 a, double2 b) { return make_doub
 // K2  winslow_apply: interior rows of one block (replaces smooth.zig:923-992 fill +
 //     BiCGStab.zig:424-435 mat-vec), matrix-free, factored row evaluation (winslow_row)
 // ------------------------------------------------------------------------------------------
-static int g_rows_per_chunk = 64;   // tunable (tm_tune_apply)
-static int g_unroll = 3;   // rows per load group: 3 or 6
+static int g_rows_per_chunk = 18;   // tunable (tm_tune_apply); short chunks: see relax2_rows_per_chunk
+static int g_unroll = 6;   // rows per load group: 3 or 6
 static int g_nt = 1;
 
 typedef double d2v __attribute__((ext_vector_type(2)));
