@@ -21,7 +21,8 @@ enum ApplyMode : int {
     MODE_DIAG_MATH = 8,      // full relax arithmetic only: no loads, no stores
     // multigrid (block-local error equation D^-1 A e = f, e = 0 on the perimeter; f arrives through `aux`)
     MODE_MG_RESID = 9,     // out = f - D^-1 A in
-    MODE_MG_SMOOTH = 10    // out = in + omega * (f - D^-1 A in)        (damped Jacobi)
+    MODE_MG_SMOOTH = 10,   // out = in + omega * (f - D^-1 A in)        (damped Jacobi)
+    MODE_MG_FIRST2 = 11    // out = omega * (2 in - omega * D^-1 A in): the first TWO damped-Jacobi sweeps from a zero guess, in = f
 };
 // ---- fused partial reductions written per workgroup (x and y components separately)
 enum DotMode : int {

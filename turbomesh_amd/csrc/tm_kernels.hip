@@ -343,6 +343,10 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
                     o.y = Wh[M].y + Wc[M].y + Wh[C].y + Wc[C].y + Wh[P3].y + Wc[P3].y;
                 } else if (MODE == MODE_DIAG_NOSTORE || MODE == MODE_DIAG_NOLOAD || MODE == MODE_DIAG_MATH) {
                     o = winslow_row<MODE_RELAX, HAS_PQ>(Wc[M], We[M], Wc[C], We[C], Wh[C], Wc[P3], We[P3], sub2(Wc[P3], Wc[M]), We[C], P, Q, a.omega, delta);
+                } else if (MODE == MODE_MG_FIRST2) {   // e1 = omega f, e2 = e1 + omega (f - D^-1 A e1) = omega (2 f - omega D^-1 A f), one pass over f
+                    const double2 t = winslow_row<MODE_SCALED, HAS_PQ>(Wc[M], We[M], Wc[C], We[C], Wh[C], Wc[P3], We[P3], sub2(Xc[P3], Xc[M]), Xdet, P, Q, 0.0,
+                                                                       delta);
+                    o = make_double2(a.omega * fma(-a.omega, t.x, 2.0 * Wc[C].x), a.omega * fma(-a.omega, t.y, 2.0 * Wc[C].y));
                 } else if (MODE == MODE_MG_RESID || MODE == MODE_MG_SMOOTH) {   // error equation of a multigrid level: frozen field in xk, rhs in aux
                     const double2 t = winslow_row<MODE_SCALED, HAS_PQ>(Wc[M], We[M], Wc[C], We[C], Wh[C], Wc[P3], We[P3], sub2(Xc[P3], Xc[M]), Xdet, P, Q, 0.0,
                                                                        delta);
@@ -819,6 +823,10 @@ hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_
     if (mode == MODE_RESID && dot == DOT_NONE) return launch_apply_md<MODE_RESID, DOT_NONE>(a, RI, nSG, nRC, st);
     if (mode == MODE_RELAX && dot == DOT_DELTA) return launch_apply_md<MODE_RELAX, DOT_DELTA>(a, RI, nSG, nRC, st);
     if (mode == MODE_RELAX && dot == DOT_NONE) return launch_apply_md<MODE_RELAX, DOT_NONE>(a, RI, nSG, nRC, st);
+    if (mode == MODE_MG_FIRST2) {
+        if (a.pq) return launch_apply_u<MODE_MG_FIRST2, DOT_NONE, false, true>(a, RI, nSG, nRC, st);
+        return launch_apply_u<MODE_MG_FIRST2, DOT_NONE, false, false>(a, RI, nSG, nRC, st);
+    }
     if (mode == MODE_MG_RESID || mode == MODE_MG_SMOOTH) {   // never field mode: the frozen coordinates are a different array
         const bool smooth = mode == MODE_MG_SMOOTH;
         if (a.pq) return smooth ? launch_apply_u<MODE_MG_SMOOTH, DOT_NONE, false, true>(a, RI, nSG, nRC, st) : launch_apply_u<MODE_MG_RESID, DOT_NONE, false, true>(a, RI, nSG, nRC, st);

@@ -152,9 +152,28 @@ void BlockMG::vcycle(const double2* f0, double2* z, double2* w0, double2* w1, hi
     };
     // ---- down
     for (size_t l = 0; l < nl; ++l) {
-        HIPCHK(launch_mg_scale(rhs[l], cur[l], L[l].ni, L[l].nj, nu_pre > 0 ? omega : 0.0, st));   // first sweep from e = 0 (also zeroes the perimeter)
-        if (l == 0 && nu_pre + nu_post > 1) HIPCHK(launch_copy_perimeter(w1, oth[0], L[0].ni, L[0].nj, st));   // the other fine iterate: zero perimeter
-        sweeps(l, pre_extra);
+        if (l == 0) {   // the two fine iterates are the caller's: make their perimeters zero (the coarse ones stay zero for good)
+            HIPCHK(launch_copy_perimeter(w1, cur[0], L[0].ni, L[0].nj, st));
+            HIPCHK(launch_copy_perimeter(w1, oth[0], L[0].ni, L[0].nj, st));
+        }
+        if (nu_pre >= 2) {   // sweeps 1 and 2 from e = 0 in one pass over f (K2, MODE_MG_FIRST2); it lands where scale + one sweep would
+            ApplyBlock a;
+            a.in = rhs[l];
+            a.xk = L[l].X;
+            a.pq = L[l].PQ;
+            a.aux = nullptr;
+            a.out = oth[l];
+            a.ni = L[l].ni;
+            a.nj = L[l].nj;
+            a.omega = omega;
+            a.partials = nullptr;
+            HIPCHK(launch_apply_block(a, MODE_MG_FIRST2, DOT_NONE, st));
+            std::swap(cur[l], oth[l]);
+            sweeps(l, pre_extra - 1);
+        } else {
+            HIPCHK(launch_mg_scale(rhs[l], cur[l], L[l].ni, L[l].nj, nu_pre > 0 ? omega : 0.0, st));   // first sweep from e = 0
+            sweeps(l, pre_extra);
+        }
         if (l + 1 == nl) {
             sweeps(l, nu_coarsest);
             break;
