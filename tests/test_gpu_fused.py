@@ -67,3 +67,31 @@ def test_fused_pairs_multiblock_large():
     a, _ = _run(build, 6, single=True)
     b, _ = _run(build, 6, single=False)
     assert np.array_equal(a, b)
+
+
+def test_config5_independent_slices_equal_separate_runs():
+    # BASELINE configs[4] (pseudo-3D: independent spanwise slices) at a small size: one handle smooths all
+    # slices concurrently (batched launches); each must equal its own single-block run bit for bit -- "replicas only"
+    nsl, n = 5, 97
+    mesh = configs.slices(nsl, n, perturb=0.2)
+    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+        sm.iterate(7)
+        sm.download()
+    for k in range(nsl):
+        one = configs.slices(1, n, first=k, perturb=0.2)
+        with smooth.Smoother(one, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+            sm.iterate(7)
+            sm.download()
+        assert np.array_equal(mesh.blocks[k].points.data, one.blocks[0].points.data), k
+    # and through the Krylov path (shared scalars: the slices' systems are solved as one block-diagonal system)
+    a = configs.slices(3, 65, perturb=0.2)
+    with smooth.Smoother(a, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-13)) as sm:
+        st = sm.iterate(2)
+        sm.download()
+    assert st["not_converged"] == 0
+    for k in range(3):
+        one = configs.slices(1, 65, first=k, perturb=0.2)
+        with smooth.Smoother(one, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-13)) as sm:
+            sm.iterate(2)
+            sm.download()
+        assert float(np.sqrt(np.mean((a.blocks[k].points.data - one.blocks[0].points.data) ** 2))) <= 2e-10

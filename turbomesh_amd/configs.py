@@ -73,6 +73,17 @@ def single_block(ni, nj=None, amplitude=0.1, tfi=None, perturb=0.0, seed=12345) 
 # ---------------------------------------------------------------------------------------------
 # config 4: strip of blocks stacked in the i direction (i <-> y, j <-> x), one interface per pair
 # ---------------------------------------------------------------------------------------------
+def slices(count, n, first=0, tfi=None, perturb=0.0) -> Mesh:
+    """SURVEY 8d config 5 (BASELINE configs[4]): `count` independent n x n single-block problems -- the spanwise cuts of a
+    pseudo-3D mesh.  Slice m has the config-2 edges with amplitude A = 0.05 + 0.001 m; no connections, so a handle smooths them
+    concurrently (one batched launch per pass) and ranks need no communication ("replicas only")."""
+    m = Mesh()
+    for k in range(first, first + count):
+        one = single_block(n, n, amplitude=0.05 + 0.001 * k, tfi=tfi, perturb=perturb, seed=12345 + k)
+        m.addBlock(f"slice_{k}", one.blocks[0])
+    return m
+
+
 def strip(nblocks, ni, nj=None, amplitude=0.1, tfi=None, reverse_odd=False, only_blocks=None) -> Mesh:
     """Block k: j_min edge (i = 0) = C_k, j_max edge (i = ni-1) = C_{k+1},
     C_k(t) = (t, k + A (1 - 2k/nblocks) sin 2 pi t).  Connections
