@@ -16,18 +16,36 @@ class NullHooks(tmd.HooksBase):
     def allreduce(self, t):
         pass
 
+import ctypes as C
+from turbomesh_amd import _capi
+from turbomesh_amd.smoothing import smooth
+
+
+class NativeNullHooks:
+    """The same with the callbacks inside the library (what the RCCL transport costs on the host, minus RCCL)."""
+
+    def __init__(self, mesh, owner, rank, world, option):
+        self._owner = (C.c_int32 * len(owner))(*owner)
+        self._hooks = _capi.tm_comm_hooks()
+        _capi.check(_capi.lib().tm_debug_null_hooks(rank, world, self._owner, C.byref(self._hooks)))
+        self.smoother = smooth.Smoother(mesh, option, None, hooks=self._hooks, stream=torch.cuda.current_stream().cuda_stream)
+
+    def iterate(self, n):
+        return self.smoother.iterate(n)
+
+
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
 steps = 200
 torch.cuda.set_device(0)
-for world in (2, 3):
+for world, cls in ((2, NullHooks), (3, NullHooks), (2, NativeNullHooks), (3, NativeNullHooks)):
     rank = 1 if world == 3 else 0      # world 3, rank 1: neighbours on both sides
     mesh = tmd.strip_for_rank(world, rank, n, n)
-    h = NullHooks(mesh, owner=list(range(world)), rank=rank, world=world, option=solver.Option.hip(inner=solver.Inner.relax))
+    h = cls(mesh, owner=list(range(world)), rank=rank, world=world, option=solver.Option.hip(inner=solver.Inner.relax))
     h.iterate(20)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     h.iterate(steps)
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
-    print(f"world {world} rank {rank}: {dt / steps * 1e6:.1f} us per sweep ({n * n * steps / dt:.3e} nodes/s) with a null transport", flush=True)
+    print(f"world {world} rank {rank} {cls.__name__}: {dt / steps * 1e6:.1f} us per sweep ({n * n * steps / dt:.3e} nodes/s) with a null transport", flush=True)
     h.smoother.close()

@@ -152,6 +152,7 @@ def lib():
         L.tm_rccl_comm_create.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         L.tm_rccl_comm_destroy.argtypes = [C.c_void_p]
         L.tm_rccl_comm_destroy.restype = None
+        L.tm_debug_null_hooks.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(tm_comm_hooks)]
         L.tm_rccl_hooks.argtypes = [C.c_void_p, C.POINTER(tm_mesh_desc), C.POINTER(C.c_int32), C.POINTER(tm_comm_hooks)]
         L.tm_plan_local.argtypes = [C.POINTER(tm_mesh_desc), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(tm_plan_local_info)]
         L.tm_plan_local_free.argtypes = [C.POINTER(tm_plan_local_info)]

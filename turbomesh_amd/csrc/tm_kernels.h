@@ -4,6 +4,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <cstdint>
+#include <vector>
 
 namespace tmh {
 
@@ -70,12 +71,18 @@ struct Relax2Block {
     int ni, nj;
     double omega;
     double* partials;   // [nwg * MAX_PARTIALS]: sum (X^(k+2) - X^(k+1))^2 over interior rows
+    const int32_t* border;   // tile ids of the BORDER workgroups (relax2_border_tiles), device array
+    int nborder;
+    int dyn;            // sides whose perimeter values change from sweep to sweep (bit 0: i = 0, 1: i = ni-1, 2: j = 0, 3: j = nj-1);
+                        // along the other sides `mid` holds constants, and workgroups touching only those count as INSIDE
 };
 bool relax2_supported(int ni, int nj);
 int relax2_rows_per_chunk(int ni, int nj);   // rows per workgroup chosen for this block on this device (fixed at handle creation)
 int relax2_block_nwg(int ni, int nj, int rows_per_chunk);
+// tile ids (row chunk * strip groups + strip group) of the workgroups a BORDER launch runs for this block and `dyn` mask
+std::vector<int32_t> relax2_border_tiles(int ni, int nj, int rows_per_chunk, int dyn);
 // Which workgroups of the K2x2 grid a launch runs.  BORDER = every workgroup with a wave that reads perimeter values of X^(k+1)
-// from `mid` or writes its first-interior ring; INSIDE = the rest (INSIDE_A / INSIDE_B: its two halves), which read nothing but
+// from `mid` or writes its first-interior ring ALONG A SIDE WHOSE PERIMETER ROWS ARE NOT ALL `fixed` (Relax2Block::dyn); INSIDE = the rest (INSIDE_A / INSIDE_B: its two halves), which read nothing but
 // interior rows of X^k -- a multi-rank handle runs them while the halo exchanges are in flight.
 enum Relax2Subset { R2_ALL = 0, R2_BORDER = 1, R2_INSIDE_A = 2, R2_INSIDE_B = 3, R2_INSIDE = 4 };
 hipError_t launch_relax2_block(const Relax2Block& a, int rows_per_chunk, int dot, int subset, hipStream_t stream);

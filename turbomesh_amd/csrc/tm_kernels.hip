@@ -596,14 +596,58 @@ __device__ __forceinline__ void relax2_strip_inside(const Relax2Block& a, const 
     for (int tb = U; tb < t.i1 - t.i0; tb += U) group(tb);
 }
 
+// Row chunks of a K2x2 block: [R2_HEAD rows][RI rows] x nf [leftover][R2_HEAD rows].  The first and the last chunk are short
+// because the workgroups that own them are the ones a multi-rank pass has to run AFTER the halo exchange, one serial chain of
+// steps each (23 us with 18 rows, measured): the shorter that chain, the sooner the next pair's interior pass starts.
+constexpr int R2_HEAD = 6;
+__host__ __device__ inline int relax2_nchunks(int ni, int RI) {
+    const int interior = ni - 2;
+    if (interior < 2 * R2_HEAD + RI) return (interior + RI - 1) / RI;   // small block: uniform chunks
+    const int nf = (interior - 2 * R2_HEAD) / RI, left = interior - 2 * R2_HEAD - nf * RI;
+    return nf + 2 + (left > 0 ? 1 : 0);
+}
+__host__ __device__ inline void relax2_chunk_rows(int ni, int RI, int rc, int& i0, int& i1) {
+    const int interior = ni - 2;
+    if (interior < 2 * R2_HEAD + RI) {
+        i0 = 1 + rc * RI;
+        i1 = (i0 + RI < ni - 1) ? i0 + RI : ni - 1;
+        return;
+    }
+    const int nf = (interior - 2 * R2_HEAD) / RI, left = interior - 2 * R2_HEAD - nf * RI;
+    if (rc == 0) {
+        i0 = 1;
+        i1 = 1 + R2_HEAD;
+    } else if (rc <= nf) {
+        i0 = 1 + R2_HEAD + (rc - 1) * RI;
+        i1 = i0 + RI;
+    } else if (left > 0 && rc == nf + 1) {
+        i0 = 1 + R2_HEAD + nf * RI;
+        i1 = i0 + left;
+    } else {
+        i0 = ni - 1 - R2_HEAD;
+        i1 = ni - 1;
+    }
+}
+
+// touches a side = reads its perimeter values from `mid` or writes the ring next to it; it matters only where those change (dyn)
+__host__ __device__ inline bool relax2_tile_is_border(int ni, int nj, int i0, int i1, int sg, int dyn) {
+    const bool top = i0 < 4, bottom = i1 + 1 > ni - 3, left = sg * 240 < 4, right = (sg * 4 + 3) * 60 + 61 > nj - 3;
+    return (top && (dyn & 1)) || (bottom && (dyn & 2)) || (left && (dyn & 4)) || (right && (dyn & 8));
+}
+
 template <int DOT, int U, bool NT, bool W1>
 __device__ __forceinline__ void relax2_tile(const Relax2Block& a, int RI, int nSG, int nRC, int subset, int bid) {
     static_assert(U % 3 == 0, "windows rotate by renaming");
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
     const int total = nSG * nRC;
-    const int q8 = total >> 3, rem = total & 7, xcd = bid & 7, k8 = bid >> 3;
-    const int logical = (xcd < rem) ? xcd * (q8 + 1) + k8 : rem * (q8 + 1) + (xcd - rem) * q8 + k8;
+    int logical;
+    if (subset == R2_BORDER) {   // compact grid: only the border tiles are launched (4000 workgroups that exit at once cost 20 us)
+        logical = a.border[bid];
+    } else {
+        const int q8 = total >> 3, rem = total & 7, xcd = bid & 7, k8 = bid >> 3;
+        logical = (xcd < rem) ? xcd * (q8 + 1) + k8 : rem * (q8 + 1) + (xcd - rem) * q8 + k8;
+    }
     const int rc = logical / nSG;
     const int sg = logical - rc * nSG;
 
@@ -612,12 +656,11 @@ __device__ __forceinline__ void relax2_tile(const Relax2Block& a, int RI, int nS
     t.c0 = (sg * 4 + wave) * 60;
     t.c = t.c0 - 2 + lane;
     t.out_lane = (lane >= 2) && (lane <= 61) && (t.c >= 1) && (t.c <= nj - 2);
-    t.i0 = 1 + rc * RI;
-    t.i1 = min(t.i0 + RI, ni - 1);
+    relax2_chunk_rows(ni, RI, rc, t.i0, t.i1);
 
-    if (subset != R2_ALL) {   // workgroup-uniform: this launch runs only part of the tiles (see Relax2Subset)
-        const bool wg_inside = (sg * 240 >= 4) && ((sg * 4 + 3) * 60 + 61 <= nj - 3) && (t.i0 >= 4) && (t.i1 + 1 <= ni - 3);
-        const bool mine = (subset == R2_BORDER) ? !wg_inside : (wg_inside && (subset == R2_INSIDE || ((subset == R2_INSIDE_A) == (rc < nRC / 2))));
+    if (subset != R2_ALL && subset != R2_BORDER) {   // workgroup-uniform: the INSIDE launches skip the border tiles
+        const bool wg_inside = !relax2_tile_is_border(ni, nj, t.i0, t.i1, sg, a.dyn);
+        const bool mine = wg_inside && (subset == R2_INSIDE || ((subset == R2_INSIDE_A) == (rc < nRC / 2)));
         if (!mine) return;   // its partial sums are written by the launch that does run it
     }
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
@@ -627,7 +670,7 @@ __device__ __forceinline__ void relax2_tile(const Relax2Block& a, int RI, int nS
         if (inside) relax2_strip_inside<DOT, U, NT, W1>(a, t, acc);
         else relax2_strip_edge<DOT, U, NT, W1>(a, t, acc);
     }
-    if (DOT != DOT_NONE) block_partials<256>(acc, a.partials + static_cast<size_t>(bid) * MAX_PARTIALS);
+    if (DOT != DOT_NONE) block_partials<256>(acc, a.partials + static_cast<size_t>(logical) * MAX_PARTIALS);   // slot = tile id in every launch flavour
 }
 
 template <int DOT, int U, bool NT, bool W1>
@@ -669,12 +712,24 @@ int relax2_rows_per_chunk(int ni, int nj) {
 bool relax2_supported(int ni, int nj) { return ni >= 5 && nj >= 5 && nj <= (1 << 20); }   // buffer-store offsets: rows_per_chunk * nj * 16 < 2^31
 int relax2_block_nwg(int ni, int nj, int RI) {
     const int nstrips = (nj - 1 + 59) / 60;
-    return ((nstrips + 3) / 4) * ((ni - 2 + RI - 1) / RI);
+    return ((nstrips + 3) / 4) * relax2_nchunks(ni, RI);
+}
+std::vector<int32_t> relax2_border_tiles(int ni, int nj, int RI, int dyn) {
+    const int nstrips = (nj - 1 + 59) / 60, nSG = (nstrips + 3) / 4, nRC = relax2_nchunks(ni, RI);
+    std::vector<int32_t> ids;
+    for (int rc = 0; rc < nRC; ++rc) {
+        int i0, i1;
+        relax2_chunk_rows(ni, RI, rc, i0, i1);
+        for (int sg = 0; sg < nSG; ++sg)
+            if (relax2_tile_is_border(ni, nj, i0, i1, sg, dyn)) ids.push_back(rc * nSG + sg);
+    }
+    return ids;
 }
 hipError_t launch_relax2_block(const Relax2Block& a, int RI, int dot, int subset, hipStream_t st) {
     const int nstrips = (a.nj - 1 + 59) / 60;
-    const int nSG = (nstrips + 3) / 4, nRC = (a.ni - 2 + RI - 1) / RI;
-    const dim3 grid(nSG * nRC), block(256);
+    const int nSG = (nstrips + 3) / 4, nRC = relax2_nchunks(a.ni, RI);
+    if (subset == R2_BORDER && a.nborder == 0) return hipSuccess;
+    const dim3 grid(subset == R2_BORDER ? a.nborder : nSG * nRC), block(256);
     const bool w1 = a.omega == 1.0;
     if (dot == DOT_DELTA) {
         if (w1) hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, true>), grid, block, 0, st, a, RI, nSG, nRC, subset);
@@ -697,12 +752,13 @@ hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_c
             B.b[q] = blocks[k];
             B.RI[q] = rows_per_chunk[k];
             B.nSG[q] = ((blocks[k].nj - 1 + 59) / 60 + 3) / 4;
-            B.nRC[q] = (blocks[k].ni - 2 + B.RI[q] - 1) / B.RI[q];
+            B.nRC[q] = relax2_nchunks(blocks[k].ni, B.RI[q]);
             B.start[q] = total;
-            total += B.nSG[q] * B.nRC[q];
+            total += (subset == R2_BORDER) ? blocks[k].nborder : B.nSG[q] * B.nRC[q];
             w1 = w1 && blocks[k].omega == 1.0;
         }
         for (int q = B.n; q < APPLY_BATCH_MAX; ++q) B.start[q] = total;
+        if (total == 0) continue;
         const dim3 grid(total), block(256);
         if (dot == DOT_DELTA) {
             if (w1) hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, true, true>), grid, block, 0, st, B, subset);

@@ -186,6 +186,19 @@ void tm_rccl_comm_destroy(tm_rccl_comm* c) {
     delete c;
 }
 
+// internal (tools/split_path_cost.py): hooks that move nothing, to time the multi-rank schedule of ONE rank without its peers.
+// The ghost rows stay stale, so the coordinates are meaningless.  Not part of the drop-in surface.
+int tm_debug_null_hooks(int32_t rank, int32_t nranks, const int32_t* owner, tm_comm_hooks* hooks) {
+    std::memset(hooks, 0, sizeof(*hooks));
+    hooks->rank = rank;
+    hooks->nranks = nranks;
+    hooks->owner = owner;
+    hooks->exchange = [](void*, const double*, double*, void*) { return 0; };
+    hooks->exchange_wait = [](void*, void*) { return 0; };
+    hooks->allreduce_sum = [](void*, double*, int32_t, void*) { return 0; };
+    return TM_OK;
+}
+
 int tm_rccl_hooks(tm_rccl_comm* c, const tm_mesh_desc* mesh, const int32_t* owner, tm_comm_hooks* hooks) {
     return guarded([&]() {
         if (!c || !mesh || !owner || !hooks) throw TmError(TM_E_ARG, "null argument");

@@ -199,53 +199,79 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
 
     // ---- perimeter rows -> device SoA with rank-local ids
     const size_t nr = lp.rows.size();
-    std::vector<int32_t> h_row(nr), h_cols(nr * 9, 0), h_metric(nr * 4, 0);
-    std::vector<int8_t> h_kind(nr), h_ncols(nr), h_slot(nr * 9, 0), h_self(nr);
-    std::vector<double> h_cx(nr * 9, 0.0), h_cy(nr * 9, 0.0), h_per(nr * 2, 0.0);
-    std::vector<uint8_t> h_flags(nr);
-    for (size_t k = 0; k < nr; ++k) {
-        const PlanRow& pr = lp.rows[k];
-        auto loc = [&](int64_t gid) {
-            const int64_t l = lp.to_local(gid);
-            if (l < 0) throw TmError(TM_E_TOPOLOGY, "internal: column is neither owned nor ghost");
-            return static_cast<int32_t>(l);
-        };
-        h_row[k] = loc(pr.gid);
-        h_kind[k] = pr.kind;
-        h_ncols[k] = pr.ncols;
-        h_self[k] = pr.self;
-        h_flags[k] = pr.flags;
-        h_per[2 * k] = pr.per[0];
-        h_per[2 * k + 1] = pr.per[1];
-        for (int q = 0; q < pr.ncols; ++q) {   // transposed: column q of all rows is contiguous
-            h_cols[q * nr + k] = loc(pr.col[q]);
-            h_cx[q * nr + k] = pr.cx[q];
-            h_cy[q * nr + k] = pr.cy[q];
-            h_slot[q * nr + k] = pr.slot[q];
-        }
-        if (pr.kind == KIND_SMOOTHED)
-            for (int q = 0; q < 4; ++q) h_metric[q * nr + k] = loc(pr.metric[q]);
-    }
     h_rhs.assign(nr * 2, 0.0);
     auto up = [&](const void* src, uint64_t bytes) -> void* {
         void* d = arena.alloc(bytes);
         if (!measure && bytes) HIPCHK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
         return d;
     };
-    edge.nrows = static_cast<int>(nr);
-    edge.row = static_cast<int32_t*>(up(h_row.data(), nr * 4));
-    edge.kind = static_cast<int8_t*>(up(h_kind.data(), nr));
-    edge.ncols = static_cast<int8_t*>(up(h_ncols.data(), nr));
-    edge.cols = static_cast<int32_t*>(up(h_cols.data(), nr * 9 * 4));
-    edge.cx = static_cast<double*>(up(h_cx.data(), nr * 9 * 8));
-    edge.cy = static_cast<double*>(up(h_cy.data(), nr * 9 * 8));
-    edge.slot = static_cast<int8_t*>(up(h_slot.data(), nr * 9));
-    edge.metric = static_cast<int32_t*>(up(h_metric.data(), nr * 4 * 4));
-    edge.per = static_cast<double*>(up(h_per.data(), nr * 2 * 8));
-    edge.flags = static_cast<uint8_t*>(up(h_flags.data(), nr));
-    edge.self = static_cast<int8_t*>(up(h_self.data(), nr));
-    d_rhs = arena.alloc_n<double>(nr * 2);
-    edge.rhs = d_rhs;
+    auto build_table = [&](const std::vector<size_t>& sel, EdgeRowsDev& e, double*& rhs_dev) {
+        const size_t n = sel.size();
+        std::vector<int32_t> h_row(n), h_cols(n * 9, 0), h_metric(n * 4, 0);
+        std::vector<int8_t> h_kind(n), h_ncols(n), h_slot(n * 9, 0), h_self(n);
+        std::vector<double> h_cx(n * 9, 0.0), h_cy(n * 9, 0.0), h_per(n * 2, 0.0);
+        std::vector<uint8_t> h_flags(n);
+        for (size_t k = 0; k < n; ++k) {
+            const PlanRow& pr = lp.rows[sel[k]];
+            auto loc = [&](int64_t gid) {
+                const int64_t l = lp.to_local(gid);
+                if (l < 0) throw TmError(TM_E_TOPOLOGY, "internal: column is neither owned nor ghost");
+                return static_cast<int32_t>(l);
+            };
+            h_row[k] = loc(pr.gid);
+            h_kind[k] = pr.kind;
+            h_ncols[k] = pr.ncols;
+            h_self[k] = pr.self;
+            h_flags[k] = pr.flags;
+            h_per[2 * k] = pr.per[0];
+            h_per[2 * k + 1] = pr.per[1];
+            for (int q = 0; q < pr.ncols; ++q) {   // transposed: column q of all rows is contiguous
+                h_cols[q * n + k] = loc(pr.col[q]);
+                h_cx[q * n + k] = pr.cx[q];
+                h_cy[q * n + k] = pr.cy[q];
+                h_slot[q * n + k] = pr.slot[q];
+            }
+            if (pr.kind == KIND_SMOOTHED)
+                for (int q = 0; q < 4; ++q) h_metric[q * n + k] = loc(pr.metric[q]);
+        }
+        e.nrows = static_cast<int>(n);
+        e.row = static_cast<int32_t*>(up(h_row.data(), n * 4));
+        e.kind = static_cast<int8_t*>(up(h_kind.data(), n));
+        e.ncols = static_cast<int8_t*>(up(h_ncols.data(), n));
+        e.cols = static_cast<int32_t*>(up(h_cols.data(), n * 9 * 4));
+        e.cx = static_cast<double*>(up(h_cx.data(), n * 9 * 8));
+        e.cy = static_cast<double*>(up(h_cy.data(), n * 9 * 8));
+        e.slot = static_cast<int8_t*>(up(h_slot.data(), n * 9));
+        e.metric = static_cast<int32_t*>(up(h_metric.data(), n * 4 * 4));
+        e.per = static_cast<double*>(up(h_per.data(), n * 2 * 8));
+        e.flags = static_cast<uint8_t*>(up(h_flags.data(), n));
+        e.self = static_cast<int8_t*>(up(h_self.data(), n));
+        rhs_dev = arena.alloc_n<double>(n * 2);
+        e.rhs = rhs_dev;
+    };
+    std::vector<size_t> all(nr);
+    for (size_t k = 0; k < nr; ++k) all[k] = k;
+    build_table(all, edge, d_rhs);
+    // Relaxation sweeps never have to touch a `fixed` row: it returns its boundary coordinate (smooth.zig:790-795), which the
+    // perimeter of every field buffer holds from upload() on.  They run the perimeter-row kernel over the other rows only
+    // (none at all for a block with fixed walls), and the K2x2 workgroups along sides without such rows do not have to wait
+    // for it.  dyn_mask: bit 0 = row i = 0 has non-fixed rows, 1 = row ni-1, 2 = column j = 0, 3 = column nj-1.
+    nf_rows.clear();
+    dyn_mask.assign(lp.owned_blocks.size(), 0);
+    for (size_t k = 0; k < nr; ++k) {
+        const PlanRow& pr = lp.rows[k];
+        if (pr.kind == KIND_FIXED) continue;
+        nf_rows.push_back(k);
+        int64_t b = topo.nblocks() - 1;
+        while (pr.gid < topo.start[b]) --b;
+        const size_t kb = std::lower_bound(lp.owned_blocks.begin(), lp.owned_blocks.end(), b) - lp.owned_blocks.begin();
+        const int64_t flat = pr.gid - topo.start[b], bi = flat / topo.nj[b], bj = flat % topo.nj[b];
+        if (bi == 0) dyn_mask[kb] |= 1;
+        if (bi == topo.ni[b] - 1) dyn_mask[kb] |= 2;
+        if (bj == 0) dyn_mask[kb] |= 4;
+        if (bj == topo.nj[b] - 1) dyn_mask[kb] |= 8;
+    }
+    if (opt.inner == TM_INNER_RELAX) build_table(nf_rows, edge_nf, d_rhs_nf);
 
     // ---- reductions
     poff.clear();
@@ -255,7 +281,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         off += apply_block_nwg(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
     }
     poff_edge = off;
-    off += edge_rows_nwg(edge.nrows);
+    off += edge_rows_nwg(opt.inner == TM_INNER_RELAX ? edge_nf.nrows : edge.nrows);   // a relax handle only ever launches the non-fixed rows
     nwg_apply = off;
     if (fuse_pairs) {
         poff2.clear();
@@ -266,9 +292,12 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
             poff2.push_back(off2);
             rows2.push_back(relax2_rows_per_chunk(bi, bj));
             off2 += relax2_block_nwg(bi, bj, rows2.back());
+            const std::vector<int32_t> ids = relax2_border_tiles(bi, bj, rows2.back(), dyn_mask[poff2.size() - 1]);
+            border_n.push_back(static_cast<int>(ids.size()));
+            border_ids.push_back(static_cast<const int32_t*>(up(ids.data(), ids.size() * 4)));
         }
         poff2_edge = off2;
-        nwg_apply2 = off2 + edge_rows_nwg(edge.nrows);
+        nwg_apply2 = off2 + edge_rows_nwg(edge_nf.nrows);
     }
     nwg_vec = vec_nwg(n_owned);
     partials = arena.alloc_n<double>(static_cast<uint64_t>(std::max(std::max(nwg_apply, nwg_apply2), nwg_vec)) * MAX_PARTIALS);
@@ -318,7 +347,28 @@ void Smoother::upload(const tm_mesh_desc* mesh) {
         }
     }
     if (!h_rhs.empty()) HIPCHK(hipMemcpyAsync(d_rhs, h_rhs.data(), sizeof(double) * h_rhs.size(), hipMemcpyHostToDevice, stream));
+    std::vector<double> h_rhs_nf(nf_rows.size() * 2);
+    if (d_rhs_nf && !nf_rows.empty()) {
+        for (size_t k = 0; k < nf_rows.size(); ++k) {
+            h_rhs_nf[2 * k] = h_rhs[2 * nf_rows[k]];
+            h_rhs_nf[2 * k + 1] = h_rhs[2 * nf_rows[k] + 1];
+        }
+        HIPCHK(hipMemcpyAsync(d_rhs_nf, h_rhs_nf.data(), sizeof(double) * h_rhs_nf.size(), hipMemcpyHostToDevice, stream));
+    }
+    if (opt.inner == TM_INNER_RELAX) prefill_fixed();
     sync();   // host staging buffers may go away after return
+}
+
+// Every field buffer of a relax handle carries the boundary coordinates on its perimeter from here on: `fixed` rows are
+// never evaluated again (their value IS this coordinate), the other perimeter rows are overwritten sweep by sweep.
+void Smoother::prefill_fixed() {
+    for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
+        const int64_t b = lp.owned_blocks[k];
+        const int64_t ls = lp.local_start[k];
+        const int bi = static_cast<int>(topo.ni[b]), bj = static_cast<int>(topo.nj[b]);
+        HIPCHK(launch_copy_perimeter(X + ls, U + ls, bi, bj, stream));
+        if (M) HIPCHK(launch_copy_perimeter(X + ls, M + ls, bi, bj, stream));
+    }
 }
 
 void Smoother::download(const tm_mesh_desc* mesh) {
@@ -410,7 +460,8 @@ void Smoother::apply(const double2* in, double2* out, int mode, int dot, const d
     // all owned blocks in one launch (groups of APPLY_BATCH_MAX): small multi-block meshes are launch-bound
     profiled([&]() { HIPCHK(launch_apply_blocks(blocks.data(), static_cast<int>(blocks.size()), mode, dot, stream)); });
     exchange_finish();   // K2 above read owned rows only; the perimeter rows below read the ghost rows
-    HIPCHK(launch_edge_rows(edge, in, xk, PQ, aux, out, omega, mode, dot, partials + static_cast<size_t>(poff_edge) * MAX_PARTIALS, stream));
+    // a relaxation sweep evaluates only the perimeter rows that are not `fixed` (see prefill_fixed)
+    HIPCHK(launch_edge_rows(mode == MODE_RELAX ? edge_nf : edge, in, xk, PQ, aux, out, omega, mode, dot, partials + static_cast<size_t>(poff_edge) * MAX_PARTIALS, stream));
     if (dot != DOT_NONE && dot != DOT_DELTA) {   // relax sweeps leave the per-workgroup partials; summed when read
         if (step >= 0) reduce_update(nwg_apply, step);
         else reduce(nwg_apply);
@@ -549,6 +600,9 @@ void Smoother::relax2_launch(int subset, bool counts, int dot) {
         a.ni = static_cast<int>(topo.ni[b]);
         a.nj = static_cast<int>(topo.nj[b]);
         a.omega = opt.omega;
+        a.dyn = dyn_mask[k];
+        a.border = border_ids[k];
+        a.nborder = border_n[k];
         a.partials = partials + static_cast<size_t>(poff2[k]) * MAX_PARTIALS;
     }
     profiled([&]() { HIPCHK(launch_relax2_blocks(blocks.data(), rows2.data(), static_cast<int>(blocks.size()), dot, subset, stream)); }, counts);
@@ -559,11 +613,11 @@ void Smoother::relax_pair(bool want_partials) {
     const int dot = want_partials ? DOT_DELTA : DOT_NONE;
     exchange(X);
     exchange_finish();
-    HIPCHK(launch_edge_rows(edge, X, X, PQ, nullptr, M, opt.omega, MODE_RELAX, DOT_NONE, partials, stream));
+    HIPCHK(launch_edge_rows(edge_nf, X, X, PQ, nullptr, M, opt.omega, MODE_RELAX, DOT_NONE, partials, stream));
     relax2_launch(R2_ALL, true, dot);
     exchange(M);
     exchange_finish();
-    HIPCHK(launch_edge_rows(edge, M, M, PQ, nullptr, U, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, stream));
+    HIPCHK(launch_edge_rows(edge_nf, M, M, PQ, nullptr, U, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, stream));
     std::swap(X, U);
 }
 
@@ -584,7 +638,7 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
         HIPCHK(hipEventCreateWithFlags(&ev_to_main, hipEventDisableTiming));
     }
     auto edge_on_side = [&](const double2* in, double2* out, int dot) {
-        HIPCHK(launch_edge_rows(edge, in, in, PQ, nullptr, out, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, side));
+        HIPCHK(launch_edge_rows(edge_nf, in, in, PQ, nullptr, out, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, side));
     };
     auto exchange_on_side = [&](double2* vec) {
         exchange(vec, side);

@@ -64,6 +64,15 @@ struct Smoother {
     EdgeRowsDev edge;
     std::vector<double> h_rhs;   // host copy of the static rhs (refilled on upload)
     double* d_rhs = nullptr;
+    // relax mode: the perimeter rows that are not `fixed` (the only ones a sweep has to evaluate), and per owned block which
+    // sides carry such rows
+    EdgeRowsDev edge_nf;
+    double* d_rhs_nf = nullptr;
+    std::vector<size_t> nf_rows;
+    std::vector<int> dyn_mask;
+    std::vector<const int32_t*> border_ids;   // per owned block: device list of the K2x2 border tiles
+    std::vector<int> border_n;
+    void prefill_fixed();   // perimeter of X -> perimeter of U and M
     // reductions
     double* partials = nullptr;
     double* red = nullptr;
