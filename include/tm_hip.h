@@ -222,7 +222,10 @@ void tm_rccl_comm_destroy(tm_rccl_comm* comm);
 int tm_rccl_hooks(tm_rccl_comm* comm, const tm_mesh_desc* mesh, const int32_t* owner /* [nblocks] */, tm_comm_hooks* hooks);
 
 /* Exchange plan of a handle created with hooks: npeers peers; for peer k, send_count[k] rows
- * (16 B each) start at send_offset[k] rows into send_buf, same for recv.  Rows are double2. */
+ * (16 B each) start at send_offset[k] rows into send_buf, same for recv.  Rows are double2.
+ * send_buf is a packed buffer -- or, when every peer's rows are one contiguous run of the rank's vector (interfaces along
+ * whole block rows), the vector itself, with send_offset[k] the run's first row: no pack kernel runs then.  Either way the
+ * hook sends send_count[k] rows from send_buf + send_offset[k]. */
 int tm_smoother_exchange_plan(const tm_smoother* s, int32_t* npeers, const int32_t** peer_rank,
                               const int64_t** send_offset, const int64_t** send_count,
                               const int64_t** recv_offset, const int64_t** recv_count);

@@ -253,7 +253,7 @@ int tm_smoother_exchange_plan(const tm_smoother* s, int32_t* npeers, const int32
         const LocalPlan& lp = s->impl.lp;
         *npeers = static_cast<int32_t>(lp.peer_rank.size());
         if (peer_rank) *peer_rank = lp.peer_rank.data();
-        if (send_offset) *send_offset = lp.send_off.data();
+        if (send_offset) *send_offset = lp.direct_send ? lp.send_first.data() : lp.send_off.data();
         if (send_count) *send_count = lp.send_cnt.data();
         if (recv_offset) *recv_offset = lp.recv_off.data();
         if (recv_count) *recv_count = lp.recv_cnt.data();

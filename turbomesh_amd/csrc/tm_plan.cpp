@@ -547,6 +547,13 @@ LocalPlan build_local_plan(const Topology& t, const std::vector<PlanRow>& all_ro
         soff += static_cast<int64_t>(send_to[r].size());
         roff += static_cast<int64_t>(recv_from[r].size());
     }
+    lp.direct_send = !lp.peer_rank.empty();
+    for (size_t k = 0; k < lp.peer_rank.size(); ++k) {
+        const int64_t o = lp.send_off[k], c = lp.send_cnt[k];
+        lp.send_first.push_back(c ? lp.send_ids[o] : 0);
+        for (int64_t q = 1; q < c; ++q)
+            if (lp.send_ids[o + q] != lp.send_ids[o] + q) lp.direct_send = false;
+    }
     if (lp.n_owned + static_cast<int64_t>(lp.ghost_gid.size()) >= (int64_t{1} << 31)) throw PlanError(TM_E_SIZE, "rank-local vector exceeds 2^31 rows");
     return lp;
 }

@@ -88,6 +88,10 @@ struct LocalPlan {
     std::vector<int32_t> peer_rank;
     std::vector<int64_t> send_off, send_cnt, recv_off, recv_cnt;
     std::vector<int32_t> send_ids;
+    // every peer's rows form ONE ascending run of local ids (true for interfaces along whole block rows, e.g. a strip of blocks): the
+    // exchange then sends straight from the vector (send_first[k] = first local id of peer k's run) and no pack kernel is needed
+    bool direct_send = false;
+    std::vector<int64_t> send_first;
     std::unordered_map<int64_t, int64_t> ghost_index;   // gid -> position in ghost_gid
     int64_t to_local(int64_t gid) const;    // -1 if neither owned nor ghost
     const Topology* topo = nullptr;

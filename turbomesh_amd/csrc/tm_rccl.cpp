@@ -208,7 +208,8 @@ int tm_rccl_hooks(tm_rccl_comm* c, const tm_mesh_desc* mesh, const int32_t* owne
             if (o < 0 || o >= c->nranks) throw TmError(TM_E_ARG, "owner rank out of range");
         const LocalPlan lp = build_local_plan(topo, build_rows(topo), c->owner, c->rank, c->nranks);
         c->peer.assign(lp.peer_rank.begin(), lp.peer_rank.end());
-        c->send_off.assign(lp.send_off.begin(), lp.send_off.end());
+        if (lp.direct_send) c->send_off.assign(lp.send_first.begin(), lp.send_first.end());   // the handle passes the vector itself as send buffer
+        else c->send_off.assign(lp.send_off.begin(), lp.send_off.end());
         c->send_cnt.assign(lp.send_cnt.begin(), lp.send_cnt.end());
         c->recv_off.assign(lp.recv_off.begin(), lp.recv_off.end());
         c->recv_cnt.assign(lp.recv_cnt.begin(), lp.recv_cnt.end());

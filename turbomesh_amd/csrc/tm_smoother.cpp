@@ -385,8 +385,12 @@ void Smoother::download(const tm_mesh_desc* mesh) {
 void Smoother::exchange(double2* vec, hipStream_t on) {
     if (!has_hooks || (n_send == 0 && n_ghost == 0)) return;
     hipStream_t st = on ? on : stream;
-    HIPCHK(launch_gather_rows(vec, d_send_ids, n_send, d_send_buf, st));
-    const int rc = hooks.exchange(hooks.ctx, reinterpret_cast<const double*>(d_send_buf), reinterpret_cast<double*>(vec + n_owned), st);
+    const double2* send = vec;   // direct: every peer's rows are one contiguous run of the vector (exchange plan offsets = local ids)
+    if (!lp.direct_send) {
+        HIPCHK(launch_gather_rows(vec, d_send_ids, n_send, d_send_buf, st));
+        send = d_send_buf;
+    }
+    const int rc = hooks.exchange(hooks.ctx, reinterpret_cast<const double*>(send), reinterpret_cast<double*>(vec + n_owned), st);
     if (rc != 0) throw TmError(TM_E_COMM, "halo exchange hook failed with code " + std::to_string(rc));
     exchange_pending = hooks.exchange_wait != nullptr;
 }

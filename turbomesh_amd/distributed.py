@@ -150,7 +150,8 @@ class HooksBase:
         self._hooks = hooks
         self.smoother = smooth.Smoother(mesh, option, control, hooks=hooks, stream=torch.cuda.current_stream(device).cuda_stream)
         self.plan = self._read_plan()
-        self.n_send = int(sum(self.plan["send_count"]))
+        # rows of the send buffer the hooks may touch: a packed buffer, or the vector itself (tm_smoother_exchange_plan)
+        self.n_send = int(max((o + c for o, c in zip(self.plan["send_offset"], self.plan["send_count"])), default=0))
         self.n_ghost = int(sum(self.plan["recv_count"]))
 
     def _read_plan(self):
