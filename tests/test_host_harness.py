@@ -45,3 +45,22 @@ def test_harness_config4_shape_runs():
     r = subprocess.run([HARNESS, "strip", "8", "256", "256", "50", "relax"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stderr
     assert "operator_sweeps 50" in r.stdout
+
+
+@pytest.mark.gpu
+def test_harness_handle_iterate_until_and_plot3d(tmp_path):
+    # the C++ mirror's device-resident handle: iterate to a residual, write PLOT3D planes transposed on the device
+    from turbomesh_amd import output
+
+    dump, p3d = str(tmp_path / "dump.bin"), str(tmp_path / "mesh.xyz")
+    r = subprocess.run([HARNESS, "strip", "2", "65", "70", "40", "mg", "until", "1e-11", "write", p3d, dump], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr
+    assert "reached 1" in r.stdout
+    got = np.fromfile(dump, dtype=np.float64).reshape(2, 65, 70, 2)
+    blocks = output.read_plot3d(p3d)
+    assert [(b[0], b[1]) for b in blocks] == [(65, 70), (65, 70)]
+    for k, (ni, nj, x, y) in enumerate(blocks):
+        assert np.array_equal(x, got[k, :, :, 0]) and np.array_equal(y, got[k, :, :, 1])
+    # a format that is not built in answers like the reference without the cgns library
+    r = subprocess.run([HARNESS, "single", "9", "9", "1", "bicgstab", "write", str(tmp_path / "m.cgns")], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "OutputFormatNotEnabled" in r.stderr

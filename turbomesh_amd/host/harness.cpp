@@ -1,8 +1,8 @@
 // harness.cpp -- plays the role of the Zig caller (reference src/gui/main.zig:30-56, src/wasm/lib.zig:35-55):
 // build edges -> Block2d.init (TFI on the MI355X) -> Mesh with connections -> smooth.mesh -> log like the reference.
 //
-//   tm_harness strip <nblocks> <ni> <nj> <iterations> [relax|bicgstab|mg] [dump.bin]
-//   tm_harness single <ni> <nj> <iterations> [relax|bicgstab|mg] [dump.bin]
+//   tm_harness strip <nblocks> <ni> <nj> <iterations> [relax|bicgstab|mg] [until <tol>] [write <file.xyz>] [dump.bin]
+//   tm_harness single <ni> <nj> <iterations> [relax|bicgstab|mg] [until <tol>] [write <file.xyz>] [dump.bin]
 //
 // The synthetic edges are those of SURVEY.md 8d (config 2 / config 4), identical to turbomesh_amd/configs.py.
 // dump.bin (optional): all block coordinates as raw f64 after smoothing, for the parity test.
@@ -92,7 +92,7 @@ static discrete::Mesh buildSingle(std::size_t ni, std::size_t nj) {
 int main(int argc, char** argv) {
     try {
         if (argc < 5) {
-            std::fprintf(stderr, "usage: %s strip <nblocks> <ni> <nj> <iterations> [relax|bicgstab|mg] [dump.bin]\n       %s single <ni> <nj> <iterations> [relax|bicgstab|mg] [dump.bin]\n", argv[0], argv[0]);
+            std::fprintf(stderr, "usage: %s strip <nblocks> <ni> <nj> <iterations> [relax|bicgstab|mg] [until <tol>] [write <file.xyz>] [dump.bin]\n       %s single <ni> <nj> <iterations> [relax|bicgstab|mg] [until <tol>] [write <file.xyz>] [dump.bin]\n", argv[0], argv[0]);
             return 2;
         }
         int a = 2;
@@ -111,7 +111,31 @@ int main(int argc, char** argv) {
         if (a < argc && (std::strcmp(argv[a], "relax") == 0 || std::strcmp(argv[a], "bicgstab") == 0 || std::strcmp(argv[a], "mg") == 0)) ++a;
         opt.rtol = 1e-13;
         opt.max_inner = 5000;
-        const tm_stats st = smoothing::smooth::mesh(mesh, iterations, opt, smoothing::wall_control_function::Algorithm::laplace());
+        // "until <tol>" after the solver name: iterate to a residual through the device-resident handle instead of a fixed count
+        double until = 0.0;
+        std::string plot3d;
+        if (a + 1 < argc && std::strcmp(argv[a], "until") == 0) {
+            until = std::strtod(argv[a + 1], nullptr);
+            a += 2;
+        }
+        if (a + 1 < argc && std::strcmp(argv[a], "write") == 0) {
+            plot3d = argv[a + 1];
+            a += 2;
+        }
+        tm_stats st{};
+        if (until > 0.0 || !plot3d.empty()) {
+            smoothing::smooth::Smoother sm(mesh, opt, smoothing::wall_control_function::Algorithm::laplace());
+            if (until > 0.0) {
+                const bool reached = sm.iterateUntil(until, iterations, &st);
+                std::printf("reached %d\n", reached ? 1 : 0);
+            } else {
+                st = sm.iterate(iterations);
+            }
+            sm.download();
+            if (!plot3d.empty()) sm.write(plot3d);
+        } else {
+            st = smoothing::smooth::mesh(mesh, iterations, opt, smoothing::wall_control_function::Algorithm::laplace());
+        }
         // the reference's log lines (smooth.zig:105, 137, 159)
         std::printf("info(smoothing): iteration: %llu\n", static_cast<unsigned long long>(st.outer_iterations ? st.outer_iterations - 1 : 0));
         std::printf("info(smoothing): \tresidual: %.17g\n", st.last_residual);

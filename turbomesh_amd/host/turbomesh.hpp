@@ -16,6 +16,7 @@
 
 #include <cmath>
 #include <cstdint>
+#include <cstdio>
 #include <limits>
 #include <optional>
 #include <stdexcept>
@@ -233,35 +234,130 @@ struct Algorithm {
 namespace smooth {
 namespace detail {
 inline tm_range toRange(const boundary::Range& r) { return tm_range{r.block, static_cast<uint32_t>(r.side), 0, r.start, r.end}; }
+inline void requirePlot3d(const std::string& filename) {   // discrete.zig:215 error.OutputFormatNotEnabled for what is not built in
+    const auto dot = filename.rfind('.');
+    const std::string ext = dot == std::string::npos ? "" : filename.substr(dot);
+    if (ext != ".xyz" && ext != ".p3d" && ext != ".x") throw Error(TM_E_UNSUPPORTED, "OutputFormatNotEnabled: " + ext + " (PLOT3D .xyz / .p3d / .x is built in; .cgns needs the cgns library)");
 }
+inline void writeHeader(std::FILE* f, const discrete::Mesh& m) {   // int32 nblocks | (int32 ni, nj) per block
+    const int32_t nb = static_cast<int32_t>(m.blocks.size());
+    std::fwrite(&nb, 4, 1, f);
+    for (const auto& b : m.blocks) {
+        const int32_t sz[2] = {static_cast<int32_t>(b.points.size[0]), static_cast<int32_t>(b.points.size[1])};
+        std::fwrite(sz, 4, 2, f);
+    }
+}
+}
+// POD description of a Mesh for the C ABI (the arrays live as long as this object)
+struct Desc {
+    std::vector<tm_block> blocks;
+    std::vector<tm_connection> conns;
+    std::vector<tm_condition> bcs;
+    tm_mesh_desc desc{};
+    explicit Desc(discrete::Mesh& mesh_data) {
+        for (auto& b : mesh_data.blocks) blocks.push_back(tm_block{&b.points.data[0].data[0], b.points.size[0], b.points.size[1]});
+        for (const auto& c : mesh_data.connections) {
+            tm_connection tc{};
+            tc.r[0] = detail::toRange(c.ranges[0]);
+            tc.r[1] = detail::toRange(c.ranges[1]);
+            tc.has_periodicity = c.periodicity ? 1 : 0;
+            if (c.periodicity) {
+                tc.periodicity[0] = c.periodicity->data[0];
+                tc.periodicity[1] = c.periodicity->data[1];
+            }
+            conns.push_back(tc);
+        }
+        for (const auto& b : mesh_data.boundary_conditions) bcs.push_back(tm_condition{detail::toRange(b.range), static_cast<uint32_t>(b.kind), 0});
+        desc = tm_mesh_desc{blocks.data(), blocks.size(), conns.data(), conns.size(), bcs.data(), bcs.size()};
+    }
+};
+inline tm_solver_opt toOpt(const solver::Option& o) {
+    return tm_solver_opt{static_cast<int32_t>(o.tag), o.inner, o.rtol, o.atol, o.max_inner, o.check_every, o.single_sweep ? uint32_t{TM_OPT_SINGLE_SWEEP} : 0u, o.omega};
+}
+inline tm_control_fn toControl(const wall_control_function::Algorithm& a) {
+    if (a.white) return tm_control_fn{TM_CF_WHITE, 0, a.white->ds_target, a.white->theta_target};
+    return tm_control_fn{TM_CF_LAPLACE, 0, 0.0, 0.0};
+}
+
 // smooth.zig:74-80: mutates mesh_data.blocks[b].points.data in place
 inline tm_stats mesh(discrete::Mesh& mesh_data, std::size_t iterations, const solver::Option& solver_option,
                      const wall_control_function::Algorithm& control_function_algorithm) {
-    std::vector<tm_block> blocks;
-    for (auto& b : mesh_data.blocks) blocks.push_back(tm_block{&b.points.data[0].data[0], b.points.size[0], b.points.size[1]});
-    std::vector<tm_connection> conns;
-    for (const auto& c : mesh_data.connections) {
-        tm_connection tc{};
-        tc.r[0] = detail::toRange(c.ranges[0]);
-        tc.r[1] = detail::toRange(c.ranges[1]);
-        tc.has_periodicity = c.periodicity ? 1 : 0;
-        if (c.periodicity) {
-            tc.periodicity[0] = c.periodicity->data[0];
-            tc.periodicity[1] = c.periodicity->data[1];
-        }
-        conns.push_back(tc);
-    }
-    std::vector<tm_condition> bcs;
-    for (const auto& b : mesh_data.boundary_conditions) bcs.push_back(tm_condition{detail::toRange(b.range), static_cast<uint32_t>(b.kind), 0});
-    tm_mesh_desc desc{blocks.data(), blocks.size(), conns.data(), conns.size(), bcs.data(), bcs.size()};
-    tm_solver_opt so{static_cast<int32_t>(solver_option.tag), solver_option.inner, solver_option.rtol, solver_option.atol, solver_option.max_inner,
-                     solver_option.check_every, solver_option.single_sweep ? uint32_t{TM_OPT_SINGLE_SWEEP} : 0u, solver_option.omega};
-    tm_control_fn cf{TM_CF_LAPLACE, 0, 0.0, 0.0};
-    if (control_function_algorithm.white) cf = tm_control_fn{TM_CF_WHITE, 0, control_function_algorithm.white->ds_target, control_function_algorithm.white->theta_target};
+    Desc d(mesh_data);
+    tm_solver_opt so = toOpt(solver_option);
+    tm_control_fn cf = toControl(control_function_algorithm);
     tm_stats st{};
-    check(tm_smooth_mesh(&desc, iterations, &so, &cf, &st));
+    check(tm_smooth_mesh(&d.desc, iterations, &so, &cf, &st));
     return st;
 }
+
+// The same smoother with the mesh resident on the device between calls (tm_smoother_*): iterate a fixed count like the
+// reference, or until the scaled nonlinear residual reaches a tolerance; write() = system.write (smooth.zig:396-414).
+class Smoother {
+   public:
+    Smoother(discrete::Mesh& mesh_data, const solver::Option& o, const wall_control_function::Algorithm& a) : mesh_(mesh_data), d_(mesh_data) {
+        tm_solver_opt so = toOpt(o);
+        tm_control_fn cf = toControl(a);
+        check(tm_smoother_create(&d_.desc, &so, &cf, nullptr, nullptr, &h_));
+    }
+    ~Smoother() { tm_smoother_destroy(h_); }
+    Smoother(const Smoother&) = delete;
+    Smoother& operator=(const Smoother&) = delete;
+    tm_stats iterate(std::size_t iterations) {
+        tm_stats st{};
+        check(tm_smoother_iterate(h_, iterations, &st));
+        return st;
+    }
+    bool iterateUntil(double scaled_residual_tol, std::size_t max_iterations, tm_stats* stats = nullptr) {
+        tm_stats st{};
+        const int rc = tm_smoother_iterate_until(h_, max_iterations, scaled_residual_tol, &st);
+        check(rc);
+        if (stats) *stats = st;
+        return rc == TM_OK;
+    }
+    void download() { check(tm_smoother_download(h_, &d_.desc)); }
+    // multi-block PLOT3D grid file (planes transposed on the device); `.cgns` needs the cgns library like the reference
+    void write(const std::string& filename) {
+        detail::requirePlot3d(filename);
+        std::FILE* f = std::fopen(filename.c_str(), "wb");
+        if (!f) throw Error(TM_E_ARG, "cannot open " + filename);
+        detail::writeHeader(f, mesh_);
+        std::vector<double> x, y;
+        for (std::size_t b = 0; b < mesh_.blocks.size(); ++b) {
+            const std::size_t n = mesh_.blocks[b].points.size[0] * mesh_.blocks[b].points.size[1];
+            x.resize(n);
+            y.resize(n);
+            check(tm_smoother_export_soa(h_, b, x.data(), y.data(), nullptr, nullptr));
+            std::fwrite(x.data(), sizeof(double), n, f);
+            std::fwrite(y.data(), sizeof(double), n, f);
+        }
+        std::fclose(f);
+    }
+
+   private:
+    discrete::Mesh& mesh_;
+    Desc d_;
+    tm_smoother* h_ = nullptr;
+};
 }  // namespace smooth
 }  // namespace smoothing
+
+namespace discrete {
+// Mesh.write (discrete.zig:197-216): one plane per coordinate with i fastest (cgns.zig:75-104), transposed on the device
+inline void write(const Mesh& m, const std::string& filename) {
+    smoothing::smooth::detail::requirePlot3d(filename);
+    std::FILE* f = std::fopen(filename.c_str(), "wb");
+    if (!f) throw Error(TM_E_ARG, "cannot open " + filename);
+    smoothing::smooth::detail::writeHeader(f, m);
+    std::vector<double> x, y;
+    for (const auto& b : m.blocks) {
+        const std::size_t n = b.points.size[0] * b.points.size[1];
+        x.resize(n);
+        y.resize(n);
+        check(tm_export_soa(&b.points.data[0].data[0], b.points.size[0], b.points.size[1], x.data(), y.data()));
+        std::fwrite(x.data(), sizeof(double), n, f);
+        std::fwrite(y.data(), sizeof(double), n, f);
+    }
+    std::fclose(f);
+}
+}  // namespace discrete
 }  // namespace core
