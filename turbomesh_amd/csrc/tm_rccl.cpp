@@ -199,6 +199,43 @@ int tm_debug_null_hooks(int32_t rank, int32_t nranks, const int32_t* owner, tm_c
     return TM_OK;
 }
 
+// internal (tools/ubench/rccl_selftest.py): device-side time of one grouped exchange of 2 x `rows` double2 with the own rank as
+// peer -- launch + handshake cost of the RCCL point-to-point path on this GPU (the wire is not exercised).
+int tm_debug_rccl_selftest(tm_rccl_comm* c, int64_t rows, int32_t iters, double* us_per_exchange) {
+    return guarded([&]() {
+        if (!c || rows <= 0 || iters <= 0 || !us_per_exchange) throw TmError(TM_E_ARG, "bad argument");
+        double *snd = nullptr, *rcv = nullptr;
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&snd), sizeof(double) * 2 * rows * 2));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&rcv), sizeof(double) * 2 * rows * 2));
+        HIPCHK(hipMemset(snd, 0, sizeof(double) * 2 * rows * 2));
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        auto once = [&]() {
+            nccl_check(g_rccl.GroupStart(), "ncclGroupStart");
+            for (int k = 0; k < 2; ++k) {   // two "neighbours", like a middle rank of a strip
+                nccl_check(g_rccl.Recv(rcv + 2 * rows * k, static_cast<size_t>(2 * rows), NCCL_FLOAT64, c->rank, c->comm, c->stream), "ncclRecv");
+                nccl_check(g_rccl.Send(snd + 2 * rows * k, static_cast<size_t>(2 * rows), NCCL_FLOAT64, c->rank, c->comm, c->stream), "ncclSend");
+            }
+            nccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
+        };
+        for (int i = 0; i < 10; ++i) once();
+        HIPCHK(hipStreamSynchronize(c->stream));
+        HIPCHK(hipEventRecord(e0, c->stream));
+        for (int i = 0; i < iters; ++i) once();
+        HIPCHK(hipEventRecord(e1, c->stream));
+        HIPCHK(hipEventSynchronize(e1));
+        float ms = 0.f;
+        HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+        *us_per_exchange = 1e3 * ms / iters;
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        (void)hipFree(snd);
+        (void)hipFree(rcv);
+        return TM_OK;
+    });
+}
+
 int tm_rccl_hooks(tm_rccl_comm* c, const tm_mesh_desc* mesh, const int32_t* owner, tm_comm_hooks* hooks) {
     return guarded([&]() {
         if (!c || !mesh || !owner || !hooks) throw TmError(TM_E_ARG, "null argument");
