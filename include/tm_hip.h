@@ -292,6 +292,10 @@ typedef struct tm_plan_local_info {
     int64_t* send_count;
     int64_t* recv_offset;    /* [npeers] rows into the ghost segment                             */
     int64_t* recv_count;
+    int64_t* send_first;     /* [npeers] first rank-local row of peer k's send list                            */
+    int32_t direct_send;     /* 1: every peer's send list is one ascending run of local rows -- a handle then sends
+                                straight from the vector (tm_smoother_exchange_plan offsets = send_first), no pack kernel */
+    int32_t _pad;
 } tm_plan_local_info;
 int tm_plan_local(const tm_mesh_desc* mesh, const int32_t* owner, int32_t rank, int32_t nranks, tm_plan_local_info* out);
 void tm_plan_local_free(tm_plan_local_info* info);

@@ -122,3 +122,19 @@ def test_strip_for_rank_matches_full_strip():
     part = configs.strip(4, 9, 12, tfi=oracle_tfi, only_blocks={2})
     assert part.blocks[0].points.data is None and part.blocks[2].points.data is not None
     assert np.array_equal(part.blocks[2].points.data, full.blocks[2].points.data)   # interface curves are bitwise reproducible per rank
+
+
+def test_direct_send_plans():
+    # a strip's interfaces run along whole block rows: each peer's send list is ONE run of local rows (one row per direction), so
+    # a handle sends straight from its vector; a 2 x 2 arrangement has column interfaces (strided rows) and keeps the pack kernel
+    strip = configs.strip(4, 9, 12, tfi=oracle_tfi, reverse_odd=True)
+    for rank in range(4):
+        p = tmd.local_plan(strip, [0, 1, 2, 3], rank, 4)
+        assert p["direct_send"] and len(p["peer_rank"]) == (1 if rank in (0, 3) else 2)
+        for k in range(len(p["peer_rank"])):
+            o, c = int(p["send_offset"][k]), int(p["send_count"][k])
+            assert c == 12                                                  # exactly one block row per neighbour
+            assert np.array_equal(p["send_ids"][o:o + c], p["send_first"][k] + np.arange(c))
+    grid = configs.two_by_two(8, 9, tfi=oracle_tfi)
+    assert not any(tmd.local_plan(grid, [0, 1, 2, 3], r, 4)["direct_send"] for r in range(4))
+    assert not tmd.local_plan(strip, [0, 0, 0, 0], 0, 1)["direct_send"]   # nobody to send to

@@ -377,6 +377,8 @@ int tm_plan_local(const tm_mesh_desc* mesh, const int32_t* owner, int32_t rank, 
         out->send_count = dup(lp.send_cnt);
         out->recv_offset = dup(lp.recv_off);
         out->recv_count = dup(lp.recv_cnt);
+        out->send_first = dup(lp.send_first);
+        out->direct_send = lp.direct_send ? 1 : 0;
         return TM_OK;
     });
 }
@@ -388,6 +390,7 @@ void tm_plan_local_free(tm_plan_local_info* i) {
     std::free(i->send_ids);
     std::free(i->send_gid);
     std::free(i->peer_rank);
+    std::free(i->send_first);
     std::free(i->send_offset);
     std::free(i->send_count);
     std::free(i->recv_offset);

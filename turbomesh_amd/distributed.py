@@ -44,7 +44,8 @@ def local_plan(mesh, owner, rank, world):
             "ghost_gid": arr(info.ghost_gid, info.n_ghost), "send_ids": arr(info.send_ids, info.n_send), "send_gid": arr(info.send_gid, info.n_send),
             "peer_rank": arr(info.peer_rank, info.npeers), "send_offset": arr(info.send_offset, info.npeers),
             "send_count": arr(info.send_count, info.npeers), "recv_offset": arr(info.recv_offset, info.npeers),
-            "recv_count": arr(info.recv_count, info.npeers),
+            "recv_count": arr(info.recv_count, info.npeers), "send_first": arr(info.send_first, info.npeers),
+            "direct_send": bool(info.direct_send),
         }
     finally:
         _capi.lib().tm_plan_local_free(C.byref(info))
