@@ -23,6 +23,8 @@ def main(argv=None):
                     help="use the hip solver with this inner strategy instead of the solver named in the file")
     ap.add_argument("--iterations", type=int, help="override smoothing.iterations")
     ap.add_argument("--output", help="override the output file (.xyz / .p3d: multi-block PLOT3D)")
+    ap.add_argument("--until", type=float, metavar="TOL",
+                    help="iterate until the scaled nonlinear residual is <= TOL (at most `iterations`, default 100) instead of a fixed count")
     args = ap.parse_args(argv)
     logging.basicConfig(level=logging.INFO, format="%(levelname)s(%(name)s): %(message)s")
 
@@ -36,7 +38,14 @@ def main(argv=None):
     geometry = inp.geometry(os.getcwd())   # profile files are named relative to the working directory, as in the reference
     mesh = inp.template.run(geometry)                                   # blocking (O4H.zig:67-118) + TFI per block
     iterations = inp.iterations if args.iterations is None else args.iterations
-    stats = smooth.mesh(mesh, iterations, inp.solver, inp.wall_control_function)
+    if args.until:
+        with smooth.Smoother(mesh, inp.solver, inp.wall_control_function) as sm:
+            reached, stats = sm.iterate_until(args.until, iterations or 100)
+            sm.download()
+        logging.getLogger("smoothing").info("scaled residual %.3e after %d iterations (%s)", stats["scaled_residual_rms"], stats["outer_iterations"],
+                                            "reached" if reached else "NOT reached")
+    else:
+        stats = smooth.mesh(mesh, iterations, inp.solver, inp.wall_control_function)
     out = args.output or inp.output
     if out:
         mesh.write(out)
