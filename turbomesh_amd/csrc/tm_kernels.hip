@@ -1469,7 +1469,11 @@ __global__ __launch_bounds__(256) void k_tfi_block(double2* __restrict__ xy, int
         uv = d2_add(uv, d2_scale(u * (1.0 - v), x_n_0));
         uv = d2_add(uv, d2_scale((1.0 - u) * v, x_0_m));
         uv = d2_add(uv, d2_scale((1.0 - u) * (1.0 - v), x_0_0));
-        xy[static_cast<size_t>(i) * m + j] = d2_sub(d2_add(u_ij, v_ij), uv);
+        const double2 o = d2_sub(d2_add(u_ij, v_ij), uv);
+        d2v ov;   // write-only stream of the whole block: non-temporal like the sweep kernels' stores
+        ov.x = o.x;
+        ov.y = o.y;
+        __builtin_nontemporal_store(ov, reinterpret_cast<d2v*>(xy + static_cast<size_t>(i) * m + j));
     }
 }
 hipError_t launch_tfi_block(double2* xy, int ni, int nj, const double2* a, const double2* b, const double2* c, const double2* d,
