@@ -110,6 +110,29 @@ _lib = None
 _dp = C.POINTER(C.c_double)
 
 
+def _share_hip_runtime():
+    """A process must run on ONE HIP runtime.  libtm_hip.so is linked against the system's libamdhip64; PyTorch ships its own
+    copy and, loaded second, finds no GPU ("No HIP GPUs are available").  When torch is installed but not imported yet, its
+    copy is loaded first so that both resolve to it -- the order every test and bench.py already has."""
+    import importlib.util
+    import sys
+
+    if "torch" in sys.modules:
+        return
+    try:
+        spec = importlib.util.find_spec("torch")
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.origin:
+        return
+    rt = os.path.join(os.path.dirname(spec.origin), "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        try:
+            C.CDLL(rt, mode=C.RTLD_GLOBAL)
+        except OSError:
+            pass
+
+
 def lib():
     """Load libtm_hip.so; raises OSError when it has not been built (no silent fallback)."""
     global _lib
@@ -117,6 +140,7 @@ def lib():
         if not os.path.exists(LIB_PATH):
             raise OSError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                           "or `make -C turbomesh_amd/csrc`; turbomesh_amd has no CPU fallback")
+        _share_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.tm_last_error.restype = C.c_char_p
         L.tm_smoother_dof.restype = C.c_uint64
