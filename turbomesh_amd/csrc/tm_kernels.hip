@@ -1443,6 +1443,30 @@ __device__ __forceinline__ double2 d2_add(double2 a, double2 b) { return make_do
 __device__ __forceinline__ double2 d2_sub(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ double2 d2_scale(double s, double2 v) { return make_double2(s * v.x, s * v.y); }
 
+// u = nu / du, v = nv / dv, IEEE-rounded.  hipcc's f64 division is div_scale x2, rcp, 4 fma (Newton), mul, fma, div_fmas,
+// div_fixup -- twice.  When du == dv and every operand is far from the ends of the exponent range (or a numerator is zero)
+// the scalings are the identity and the fix-up passes the value through, so ONE reciprocal refinement serves both quotients
+// and each costs mul + 2 fma more: the same bits (see recip_diag).  Anything else takes the plain divisions (wave-uniform).
+__device__ __forceinline__ void div_pair(double nu, double nv, double du, double dv, double& u, double& v) {
+    const double au = fabs(nu), av = fabs(nv), ad = fabs(du);
+    const bool plain = (du == dv) && (ad >= 0x1p-500) && (ad <= 0x1p500) && (au == 0.0 || (au >= 0x1p-500 && au <= 0x1p500)) &&
+                       (av == 0.0 || (av >= 0x1p-500 && av <= 0x1p500));
+    if (__builtin_amdgcn_ballot_w64(!plain) == 0) {
+        const double nd = -du;
+        const double r0 = __builtin_amdgcn_rcp(du);
+        const double e0 = fma(nd, r0, 1.0);
+        const double r1 = fma(r0, e0, r0);
+        const double e1 = fma(nd, r1, 1.0);
+        const double r2 = fma(r1, e1, r1);
+        const double qu = nu * r2, qv = nv * r2;
+        u = fma(fma(nd, qu, nu), r2, qu);
+        v = fma(fma(nd, qv, nv), r2, qv);
+        return;
+    }
+    u = nu / du;
+    v = nv / dv;
+}
+
 __global__ __launch_bounds__(256) void k_tfi_block(double2* __restrict__ xy, int n, int m, const double2* __restrict__ x_i_min,
                                                    const double2* __restrict__ x_i_max, const double2* __restrict__ x_j_min,
                                                    const double2* __restrict__ x_j_max, const double* __restrict__ s1,
@@ -1460,8 +1484,11 @@ __global__ __launch_bounds__(256) void k_tfi_block(double2* __restrict__ xy, int
         if (i >= n) break;
         const double s1_i = s1[i], s2_i = s2[i];
         const double2 x_i_0 = x_i_min[i], x_i_m = x_i_max[i];
-        const double u = ((1.0 - t1_j) * s1_i + t1_j * s2_i) / (1.0 - (s2_i - s1_i) * (t2_j - t1_j));   // tfi.zig:185
-        const double v = ((1.0 - s1_i) * t1_j + s1_i * t2_j) / (1.0 - (t2_j - t1_j) * (s2_i - s1_i));   // tfi.zig:186
+        // tfi.zig:185-186: u = nu / (1 - (s2-s1)(t2-t1)), v = nv / (1 - (t2-t1)(s2-s1)) -- the two denominators are the same
+        // number (one IEEE product, either order); both quotients correctly rounded like the reference's divisions
+        double u, v;
+        div_pair((1.0 - t1_j) * s1_i + t1_j * s2_i, (1.0 - s1_i) * t1_j + s1_i * t2_j, 1.0 - (s2_i - s1_i) * (t2_j - t1_j),
+                 1.0 - (t2_j - t1_j) * (s2_i - s1_i), u, v);
         const double2 u_ij = d2_add(d2_scale(1.0 - u, x_0_j), d2_scale(u, x_n_j));
         const double2 v_ij = d2_add(d2_scale(1.0 - v, x_i_0), d2_scale(v, x_i_m));
         double2 uv = make_double2(0.0, 0.0);
