@@ -87,6 +87,9 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-solve", action="store_true", help="skip the (untimed) solve-to-1e-8 report")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (RCCL hooks) even with one rank")
+    ap.add_argument("--verify", action="store_true",
+                    help="after the timed region: gather every rank's block on rank 0 and compare it, bit for bit, with a single-handle run of the "
+                         "whole strip over the same number of sweeps (small sizes; used by the multi-process rehearsals)")
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
                     help="halo exchange: the library's own RCCL transport (default) or torch.distributed p2p from Python hooks")
     ap.add_argument("--rows", type=int, default=0, help="K2 rows per chunk (tuning)")
@@ -195,6 +198,24 @@ def main():
     k2_ms, k2_launches = sm.profile_read()
     sm.profile(False)
 
+    verified = None
+    if args.verify and dist is not None:
+        sm.download()
+        mine = torch.from_numpy(mesh.blocks[rank].points.data.copy())
+        parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
+        if dist.get_backend() == "nccl":
+            mine = mine.cuda()
+            parts = [p.cuda() for p in parts] if parts else None
+        dist.gather(mine, parts, dst=0)
+        if rank == 0:
+            whole = configs.strip(world, n, n)
+            with smooth.Smoother(whole, relax_opt) as ref:
+                ref.iterate(args.warmup)
+                ref.iterate(args.steps)
+                ref.download()
+            verified = all(np.array_equal(parts[b].cpu().numpy(), whole.blocks[b].points.data) for b in range(world))
+            print(f"[bench] --verify: {world} ranks vs one handle after {args.warmup}+{args.steps} sweeps: {'bit-identical' if verified else 'MISMATCH'}", file=sys.stderr)
+
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
@@ -223,7 +244,7 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "nodes_per_gpu": n * n, "solver": "hip/relax (fused Jacobi elliptic sweep" + (", two sweeps per kernel pass)" if fused else ")"), "omega": 1.0,
-                       "residual_last": st["last_residual"], "whole_job_GBps_algorithmic": BYTES_PER_NODE * value / 1e9},
+                       "residual_last": st["last_residual"], **({"verified_against_single_handle": verified} if verified is not None else {}), "whole_job_GBps_algorithmic": BYTES_PER_NODE * value / 1e9},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic,
                          "kernel": "k_relax2<DELTA> (K2x2: two winslow sweeps per launch)" if fused else "k_apply<RELAX,DELTA,field,laplace> (K2 winslow_apply)",
