@@ -246,6 +246,13 @@ static int g_unroll = 6;   // rows per load group: 3 or 6
 static int g_nt = 1;
 
 typedef double d2v __attribute__((ext_vector_type(2)));
+// streaming store of a double2 (the vectors are far larger than the caches; worth +25 % on a copy of this footprint)
+__device__ __forceinline__ void store_nt(double2* dst, double2 v) {
+    d2v o;
+    o.x = v.x;
+    o.y = v.y;
+    __builtin_nontemporal_store(o, reinterpret_cast<d2v*>(dst));
+}
 
 // One workgroup's tile of one block; `bid` = the workgroup's index within that block's tiles (also its partial-sum slot).
 template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool NT>
@@ -1330,7 +1337,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_p_update(const KrylovScalars* __r
     const double bx = S->beta[0], by = S->beta[1], ox = S->omega[0], oy = S->omega[1];
     for (int64_t i = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * VEC_BLOCK) {
         const double2 ri = r[i], pi = p[i], vi = v[i];
-        p[i] = make_double2(ri.x + bx * (pi.x - ox * vi.x), ri.y + by * (pi.y - oy * vi.y));   // BiCGStab.zig:310-312
+        store_nt(p + i, make_double2(ri.x + bx * (pi.x - ox * vi.x), ri.y + by * (pi.y - oy * vi.y)));   // BiCGStab.zig:310-312
     }
 }
 hipError_t launch_p_update(const KrylovScalars* S, const double2* r, double2* p, const double2* v, int64_t n, hipStream_t st) {
@@ -1346,7 +1353,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_s_update(const KrylovScalars* __r
     for (int64_t i = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * VEC_BLOCK) {
         const double2 ri = r[i], vi = v[i];
         const double2 si = make_double2(ri.x - ax * vi.x, ri.y - ay * vi.y);   // BiCGStab.zig:325-327
-        s[i] = si;
+        store_nt(s + i, si);
         acc[0] += si.x * si.x;
         acc[1] += si.y * si.y;
     }
@@ -1370,9 +1377,9 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_xr_update(const KrylovScalars* __
         ui.y += ay * pi.y;
         ui.x += ox * sh.x;   // BiCGStab.zig:352-354 (x += omega * s_hat)
         ui.y += oy * sh.y;
-        u[i] = ui;
+        store_nt(u + i, ui);
         const double2 ri = make_double2(si.x - ox * ti.x, si.y - oy * ti.y);   // BiCGStab.zig:356-358
-        r[i] = ri;
+        store_nt(r + i, ri);
         acc[0] += rh.x * ri.x;
         acc[1] += rh.y * ri.y;
         acc[2] += ri.x * ri.x;
