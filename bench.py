@@ -7,63 +7,156 @@ node, with Jacobi scaling, the relaxation update, the perimeter (constraint / in
 rows and the residual-norm partial reduction -- i.e. one outer iteration of the `hip` solver
 in TM_INNER_RELAX mode, run through the C-ABI handle with the coordinates resident in HBM.
 
-  N = 1  : BASELINE configs[1] -- single synthetic 4096 x 4096 block, TFI seeded on the GPU.
-  N > 1  : weak scaling -- a strip of N such blocks stacked in i, one per GPU, coupled by
-           interface rows exchanged with torch.distributed (RCCL) point-to-point every sweep.
+  --config 2 (default)  N = 1: BASELINE configs[1] -- single synthetic 4096 x 4096 block, TFI
+                        seeded on the GPU.  N > 1: weak scaling -- a strip of N such blocks stacked in i, one per GPU,
+                        coupled by interface rows exchanged point-to-point (RCCL over xGMI) between sweeps.
+  --config 4            BASELINE configs[3], STRONG scaling: 8 coupled blocks of 2048^2, 8/N blocks per GPU.
+  --config 5            BASELINE configs[4]: independent 2048^2 slices, 8 per GPU ("replicas only": no communication).
 
-Prints ONE JSON line on rank 0 (see the contract in the task description)."""
+`python bench.py --gpus N` starts its own N ranks (one process per GPU, torch.distributed.run as a child process)
+when it is not already running under a launcher.  Prints ONE JSON line on rank 0."""
 from __future__ import annotations
 
 import argparse
+import hashlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; 6.29 TB/s measured copy)
-BYTES_PER_NODE = 32.0         # algorithmic traffic of a Laplace field sweep: read one double2, write one double2 (SURVEY 8d)
+HBM_PEAK_GBPS = 8000.0        # MI355X HBM3E spec peak (MI355X_MICROARCH.md: 8.0 TB/s; ~6.3 TB/s measured copy)
+BYTES_PER_NODE = 32.0         # compulsory traffic of one pass over a Laplace field: read one double2, write one double2 (SURVEY 8d)
+PROFILE_EVERY = 4             # a hipEvent pair brackets every 4th launch of the dominant kernel inside the timed region
 
 
-def cpu_baseline(n, budget_s=15.0):
-    """The oracle's matrix-free sweep (same arithmetic, -O2, single thread) on the host cores of this box,
-    on a bounded sample: whole 4096^2 sweeps until ~budget_s of CPU work."""
+def kernels_hash():
+    """Identifies the kernel source a PMC measurement belongs to (profiles/traffic.json carries the hash it was taken with)."""
+    with open(os.path.join(ROOT, "turbomesh_amd", "csrc", "tm_kernels.hip"), "rb") as f:
+        return hashlib.sha256(f.read()).hexdigest()[:16]
+
+
+# ------------------------------------------------------------------------------------------------------------------
+# cpu_baseline: the oracle (a C++ restatement of the reference's Zig; the reference itself cannot be built here) timed
+# on this box's host cores, bounded samples.  Only this function touches oracle/.
+# ------------------------------------------------------------------------------------------------------------------
+def cpu_baseline(n, budget_s=15.0, with_t106=True):
+    """value = the reference's own per-outer-iteration path (CSR fill + BiCGStab with the diagonal preconditioner + residual +
+    copy-back, smooth.zig:104-154, BiCGStab.zig:279-370) in node-operator-applications per second, 1 thread, on a
+    sub-block of the workload; the stages, GMRES(30)+ILU(0) (what examples/T106/T106.json selects), the T106 JSON as written
+    and the matrix-free mirror sweep (the same unit of work as the GPU step) are reported as structured keys beside it."""
     import numpy as np
 
     from oracle import oracle
-
-    e_n = n
-    # seed on the CPU (oracle TFI) -- the baseline leg must not depend on the GPU
     from turbomesh_amd import configs
 
     def tfi_cpu(i_min, i_max, j_min, j_max):
         return configs.block_from_array(oracle.tfi_block(i_min.points, i_max.points, j_min.points, j_max.points, i_min.clustering,
                                                           i_max.clustering, j_min.clustering, j_max.clustering))
 
-    mesh = configs.single_block(e_n, e_n, tfi=tfi_cpu)
+    t0 = time.perf_counter()
+    mesh = configs.single_block(n, n, tfi=tfi_cpu)
+    t_tfi = time.perf_counter() - t0          # includes building the four edges (numpy), dominated by the TFI loop
     xy = mesh.blocks[0].points.data
-    t1 = oracle.time_relax_sweeps(xy, 1)          # warm-up + calibration
-    sweeps = max(1, min(512, int(budget_s / max(t1, 1e-3))))
+
+    # ---- the reference's path, stage by stage, on a sub-block (the CSR + GMRES basis of 4096^2 need ~8 GB and minutes)
+    m = min(n, 2048 if budget_s >= 5 else 257)
+    sub = np.ascontiguousarray(xy[:m, :m]).copy()
+    bi, gi = (8, 10) if budget_s >= 5 else (3, 4)
+    st = oracle.time_reference_path(sub, bi, gi)
+    nodes = float(m * m)
+    bic_apps = 2 * st["bicgstab_iterations"] + 1                 # 2 mat-vecs per iteration + the initial residual
+    gm_apps = st["gmres_iterations"] + 1
+    path_s = st["fill_s"] + st["bicgstab_diag_s"] + st["residual_copyback_s"]
+    stages = {
+        "sample_block": f"{m}x{m} sub-block of the {n}x{n} workload, x-system (BiCGStab) / y-system (GMRES), 1 thread",
+        "tfi": {"seconds": t_tfi, "nodes_per_s": n * n / t_tfi, "what": f"tfi.zig:112-208 on the {n}x{n} block"},
+        "init": {"seconds": st["init_s"], "what": "RowCompressedMatrixSystem2d.init (pattern, row kinds, static rows), once per smooth.mesh call"},
+        "fill": {"seconds": st["fill_s"], "nodes_per_s": nodes / st["fill_s"], "what": "system.fill: 9 coefficients per row, smooth.zig:923-1113"},
+        "bicgstab_diag": {"seconds": st["bicgstab_diag_s"], "iterations": st["bicgstab_iterations"],
+                          "node_matvecs_per_s": nodes * bic_apps / st["bicgstab_diag_s"], "what": "BiCGStab.zig:279-370, one component"},
+        "gmres30_ilu0": {"seconds": st["gmres30_ilu0_s"], "iterations": st["gmres_iterations"], "ilu0_factor_seconds": st["ilu0_factor_s"],
+                         "node_matvecs_per_s": nodes * gm_apps / st["gmres30_ilu0_s"],
+                         "what": "GMRES.zig:300-423 + ILU(0) GMRES.zig:199-298, one component (the solver of examples/T106/T106.json)"},
+        "residual_copyback": {"seconds": st["residual_copyback_s"], "nodes_per_s": nodes / st["residual_copyback_s"], "what": "smooth.zig:112-153"},
+    }
+
+    # ---- the matrix-free mirror sweep: the GPU step's own unit of work on the CPU (NOT something the reference executes)
+    t1 = oracle.time_relax_sweeps(xy, 1)
+    sweeps = max(1, min(512, int(0.4 * budget_s / max(t1, 1e-3))))
     t = oracle.time_relax_sweeps(xy, sweeps)
-    # reference-style inner iteration for context: assembled CSR + BiCGStab(diagonal), 2 mat-vecs per iteration
-    sub = configs.single_block(1024, 1024, tfi=tfi_cpu).blocks[0].points.data
-    tb, _ = oracle.time_bicgstab_iterations(sub, 4)
-    # the same sweeps on the CPU share this process may use (NOT the reference's behaviour: it is single-threaded, SURVEY F1)
     threads = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
     threads = max(1, min(threads, 64))
     t1m = oracle.time_relax_sweeps_mt(xy, 2, threads)
-    sweeps_m = max(2, min(2048, int(6.0 / max(t1m / 2, 1e-4))))   # ~6 s
+    sweeps_m = max(2, min(2048, int(0.3 * budget_s / max(t1m / 2, 1e-4))))
     tm = oracle.time_relax_sweeps_mt(xy, sweeps_m, threads)
-    return {
-        "all_threads": {"value": e_n * e_n * sweeps_m / tm, "unit": "nodes/s", "cores": threads,
-                        "sample": f"{sweeps_m} sweeps, rows of each sweep split over {threads} threads ({tm:.1f} s); not the reference's behaviour"},
-        "value": e_n * e_n * sweeps / t, "unit": "nodes/s", "cores": 1, "kind": "port",
-        "sample": f"{sweeps} Jacobi elliptic sweeps of the {e_n}x{e_n} block by the C++ oracle (g++ -O2 -ffp-contract=off, 1 thread, "
-                  f"{t:.1f} s); reference-style CSR BiCGStab(diagonal) on 1024^2: {1024 * 1024 * 8 / tb:.3e} node-matvecs/s",
-        "host_cpus": os.cpu_count(),
+    mirror = {"value": n * n * sweeps / t, "unit": "nodes/s", "cores": 1,
+              "sample": f"{sweeps} matrix-free Jacobi elliptic sweeps of the {n}x{n} block (oracle/orc_mirror.cpp, g++ -O2 -ffp-contract=off, {t:.1f} s)",
+              "all_threads": {"value": n * n * sweeps_m / tm, "cores": threads, "sample": f"{sweeps_m} sweeps, rows split over {threads} threads ({tm:.1f} s)"}}
+
+    out = {
+        "value": nodes * bic_apps / path_s, "unit": "nodes/s", "cores": 1, "kind": "port",
+        "sample": (f"one outer iteration of the reference path on a {m}x{m} sub-block: fill + {st['bicgstab_iterations']} BiCGStab(diagonal) "
+                   f"iterations ({bic_apps} operator applications) + residual/copy-back, {path_s:.1f} s; C++ restatement (g++ -O2 "
+                   "-ffp-contract=off), the Zig reference cannot be built in this image"),
+        "stages": stages, "mirror_sweep": mirror, "host_cpus": os.cpu_count(),
     }
+    if with_t106:
+        out["t106_json_as_written"] = t106_cpu()
+    return out
+
+
+def _t106_load(tfi):
+    from turbomesh_amd.input import Input
+
+    gold = os.path.join(ROOT, "tests", "golden")
+    inp = Input.parse(open(os.path.join(gold, "examples", "T106", "T106.json")).read())
+    return inp, inp.template.run(inp.geometry(gold), tfi=tfi)
+
+
+def t106_cpu():
+    """BASELINE configs[0]: examples/T106/T106.json as written (8 blocks, 25 118 nodes, 10 iterations, GMRES+ILU0, white) on the oracle."""
+    import numpy as np
+
+    from oracle import oracle
+    from turbomesh_amd import configs
+
+    def tfi_cpu(i_min, i_max, j_min, j_max):
+        return configs.block_from_array(oracle.tfi_block(i_min.points, i_max.points, j_min.points, j_max.points, i_min.clustering,
+                                                          i_max.clustering, j_min.clustering, j_max.clustering))
+
+    class OM:
+        def __init__(self, mesh):
+            self.blocks = [np.array(b.points.data, dtype=np.float64, order="C", copy=True) for b in mesh.blocks]
+            self.connections = [((c.ranges[0].block, int(c.ranges[0].side), c.ranges[0].start, c.ranges[0].end),
+                                 (c.ranges[1].block, int(c.ranges[1].side), c.ranges[1].start, c.ranges[1].end),
+                                 None if c.periodicity is None else tuple(c.periodicity)) for c in mesh.connections]
+            self.bcs = [((b.range.block, int(b.range.side), b.range.start, b.range.end), int(b.kind)) for b in mesh.boundary_conditions]
+
+    inp, mesh = _t106_load(tfi_cpu)
+    w = inp.wall_control_function.white
+    om = OM(mesh)
+    t0 = time.perf_counter()
+    st = oracle.smooth_mesh(om, inp.iterations, solver=oracle.SOLVER_GMRES, preconditioner=oracle.PRECOND_ILU0, control=("white", w.ds_target, w.theta_target))
+    dt = time.perf_counter() - t0
+    return {"cpu_seconds": dt, "outer_iterations": int(st.outer_iterations), "inner_iterations": int(st.inner_iterations),
+            "nodes": int(sum(b.shape[0] * b.shape[1] for b in om.blocks)), "solver": "gmres(30) + ilu0, white control function (the JSON as written)",
+            "nodes_per_s": sum(b.shape[0] * b.shape[1] for b in om.blocks) * inp.iterations / dt}
+
+
+def t106_gpu(smooth, solver, wcf):
+    """The same job on the GPU: TFI of the 8 blocks + 10 Picard iterations with the white control function, hip solver."""
+    t0 = time.perf_counter()
+    inp, mesh = _t106_load(None)
+    t_tfi = time.perf_counter() - t0
+    w = inp.wall_control_function.white
+    with smooth.Smoother(mesh, solver.Option.hip(rtol=1e-8, max_inner=20000), wcf.Algorithm(wcf.White(w.ds_target, w.theta_target))) as sm:
+        st = sm.iterate(inp.iterations)
+    return {"gpu_seconds": st["seconds"], "tfi_and_blocking_seconds": t_tfi, "outer_iterations": st["outer_iterations"], "inner_iterations": st["inner_iterations"],
+            "not_converged": st["not_converged"], "solver": "hip/bicgstab (diagonal scaling), rtol 1e-8 on the scaled residual, white control function"}
 
 
 def solve_to_tolerance(n, smooth, solver, configs, tol=1e-8):
@@ -78,17 +171,37 @@ def solve_to_tolerance(n, smooth, solver, configs, tol=1e-8):
             "solver": "hip/mg_bicgstab (Picard + BiCGStab, one multigrid V(2,2) cycle per block as preconditioner)"}
 
 
+def self_launch(args):
+    """--gpus N without a launcher: start N fresh ranks as a CHILD process (this process has not touched the GPU and never
+    will) and relay rank 0's JSON line."""
+    import socket
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    r = subprocess.run(cmd, stdout=subprocess.PIPE, env=env)
+    lines = [l for l in r.stdout.decode(errors="replace").splitlines() if l.lstrip().startswith("{")]
+    if lines:
+        print(lines[-1], flush=True)
+    raise SystemExit(r.returncode if r.returncode else (0 if lines else 1))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--size", dest="n", type=int, default=4096, help="block edge (nodes); 4096 is the BASELINE config")
+    ap.add_argument("--config", type=int, default=2, choices=[2, 4, 5], help="SURVEY 8d config: 2 = 4096^2 block(s) (default), 4 = 8 x 2048^2 strip strong scaling, 5 = independent 2048^2 slices")
+    ap.add_argument("--size", dest="n", type=int, default=0, help="block edge (nodes); default 4096 (config 2) / 2048 (configs 4, 5)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-solve", action="store_true", help="skip the (untimed) solve-to-1e-8 report")
+    ap.add_argument("--no-solve", action="store_true", help="skip the (untimed) solve-to-1e-8 and T106 reports")
     ap.add_argument("--force-dist", action="store_true", help="run the multi-GPU code path (RCCL hooks) even with one rank")
     ap.add_argument("--verify", action="store_true",
-                    help="after the timed region: gather every rank's block on rank 0 and compare it, bit for bit, with a single-handle run of the "
+                    help="after the timed region: gather every rank's blocks on rank 0 and compare them, bit for bit, with a single-handle run of the "
                          "whole strip over the same number of sweeps (small sizes; used by the multi-process rehearsals)")
     ap.add_argument("--transport", choices=["rccl", "torch"], default="rccl",
                     help="halo exchange: the library's own RCCL transport (default) or torch.distributed p2p from Python hooks")
@@ -98,7 +211,11 @@ def main():
     ap.add_argument("--nt", type=int, default=-1, help="K2 non-temporal stores 0/1 (tuning)")
     ap.add_argument("--single-sweep", action="store_true", help="one kernel pass per sweep (K2) instead of two sweeps per pass (K2x2)")
     ap.add_argument("--fuse-rows", type=int, default=0, help="K2x2 rows per chunk (tuning)")
+    ap.add_argument("--profile-every", type=int, default=PROFILE_EVERY, help="bracket every k-th launch of the dominant kernel with a hipEvent pair")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ and not args.force_dist:
+        self_launch(args)   # does not return
 
     # Libraries (RCCL prints a version banner) write to fd 1; the contract is ONE JSON line on stdout, so everything
     # else goes to stderr and the JSON is written to the saved descriptor at the end.
@@ -112,27 +229,28 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if args.gpus != world:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N")
+    if args.gpus != world and rank == 0:
+        print(f"[bench] --gpus {args.gpus} but the launcher started {world} rank(s): reporting n_gpus = {world}", file=sys.stderr)
     assert torch.cuda.is_available(), "bench.py needs the MI355X (no CPU fallback)"
     if os.environ.get("TM_BENCH_SAME_DEVICE"):   # rehearsal of the multi-rank path on a one-GPU box
         local_rank = 0
     torch.cuda.set_device(local_rank)
 
     from turbomesh_amd import _capi, configs
-    from turbomesh_amd.smoothing import smooth, solver
+    from turbomesh_amd.smoothing import smooth, solver, wall_control_function as wcf
 
     if args.rows or args.unroll or args.pipe >= 0 or args.nt >= 0:
         _capi.lib().tm_tune_apply(args.rows, args.unroll, args.pipe, args.nt)
-
     if args.fuse_rows:
         _capi.lib().tm_tune_fuse(args.fuse_rows)
     relax_opt = solver.Option.hip(inner=solver.Inner.relax, single_sweep=args.single_sweep)
 
-    n = args.n
+    n = args.n or (4096 if args.config == 2 else 2048)
+    scaling = "strong" if args.config == 4 else "weak"
     dist = None
     hooks_obj = None
+    owned = [0]
+    coupled = args.config != 5 and (world > 1 or args.force_dist)
     if world > 1 or args.force_dist:
         import torch.distributed as dist_mod
 
@@ -144,30 +262,57 @@ def main():
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", local_rank))
         else:
             dist.init_process_group(backend, rank=rank, world_size=world)
+
+    if args.config == 5:
+        per_rank = 8
+        nblocks_total = per_rank * world
+        mesh = configs.slices(per_rank, n, first=rank * per_rank)          # this rank's slices; nobody else's exist here
+        owned = list(range(per_rank))
+        sm = smooth.Smoother(mesh, relax_opt, stream=torch.cuda.current_stream().cuda_stream)
+        workload = (f"{nblocks_total} independent {n}x{n} slices (SURVEY 8d config 5), {per_rank} per GPU in one handle, replicas only "
+                    "(no communication)")
+    elif coupled:
         from turbomesh_amd import distributed as tmd
 
-        mesh = tmd.strip_for_rank(world, rank, n, n)                        # only the owned block carries coordinates
-        owner = list(range(world))
+        if args.config == 4:
+            nblocks_total = 8
+            if nblocks_total % world:
+                raise SystemExit("--config 4 shards 8 blocks: --gpus must divide 8")
+            bpr = nblocks_total // world
+        else:
+            nblocks_total, bpr = world, 1
+        mesh = tmd.strip_for_rank(world, rank, n, n, blocks_per_rank=bpr)   # only the owned blocks carry coordinates
+        owner = [b // bpr for b in range(nblocks_total)]
+        owned = [b for b in range(nblocks_total) if owner[b] == rank]
         transport = "torch.distributed p2p (Python hooks)"
         if backend == "nccl" and args.transport == "rccl":
-            # the library's own RCCL transport; checked once against the torch.distributed hooks on a small strip
-            # (same sweeps, bit-identical coordinates expected) -- every rank takes the same decision
+            # The library's own RCCL transport.  Every rank first checks what it can check ALONE (librccl loads, its symbols
+            # resolve, a unique id can be made) and the ranks vote BEFORE any collective call: a rank that failed locally
+            # would otherwise leave the others blocked inside ncclCommInitRank.  Then the transport is checked once against
+            # the torch.distributed hooks on a small strip (same sweeps, bit-identical coordinates expected).
             ok, why = 1, ""
             try:
-                small = [tmd.strip_for_rank(world, rank, 192, 256) for _ in range(2)]
-                h_a = tmd.RcclHooks(small[0], owner=owner, rank=rank, world=world, option=relax_opt)
-                h_b = tmd.TorchHooks(small[1], owner=owner, rank=rank, world=world, option=relax_opt)
-                for h in (h_a, h_b):
-                    h.iterate(5)
-                    h.smoother.download()
-                ok = int(np.array_equal(small[0].blocks[rank].points.data, small[1].blocks[rank].points.data))
-                why = "" if ok else "coordinates differ from the torch.distributed transport"
-                h_a.close()
-                h_b.smoother.close()
-            except Exception as e:   # noqa: BLE001 -- any failure means: use the other transport
+                tmd.RcclHooks.precheck()
+            except Exception as e:   # noqa: BLE001
                 ok, why = 0, repr(e)
             flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag.item()) == 1:
+                try:
+                    small = [tmd.strip_for_rank(world, rank, 192, 256, blocks_per_rank=bpr) for _ in range(2)]
+                    h_a = tmd.RcclHooks(small[0], owner=owner, rank=rank, world=world, option=relax_opt)
+                    h_b = tmd.TorchHooks(small[1], owner=owner, rank=rank, world=world, option=relax_opt)
+                    for h in (h_a, h_b):
+                        h.iterate(5)
+                        h.smoother.download()
+                    ok = int(all(np.array_equal(small[0].blocks[b].points.data, small[1].blocks[b].points.data) for b in owned))
+                    why = "" if ok else "coordinates differ from the torch.distributed transport"
+                    h_a.close()
+                    h_b.smoother.close()
+                except Exception as e:   # noqa: BLE001 -- any failure means: use the other transport
+                    ok, why = 0, repr(e)
+                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
                 hooks_obj = tmd.RcclHooks(mesh, owner=owner, rank=rank, world=world, option=relax_opt)
                 transport = "RCCL p2p issued by libtm_hip (tm_rccl_*)"
@@ -176,8 +321,16 @@ def main():
         if hooks_obj is None:
             hooks_obj = tmd.TorchHooks(mesh, owner=owner, rank=rank, world=world, option=relax_opt)
         sm = hooks_obj.smoother
-        workload = f"strip of {world} blocks {n}x{n}, one per GPU, interface rows exchanged by {transport} every sweep"
+        workload = (f"strip of {nblocks_total} coupled blocks {n}x{n} (SURVEY 8d config {args.config}), {bpr} per GPU, interface rows exchanged by "
+                    f"{transport} between sweeps")
+    elif args.config == 4:
+        nblocks_total = 8
+        mesh = configs.strip(nblocks_total, n, n)
+        owned = list(range(nblocks_total))
+        sm = smooth.Smoother(mesh, relax_opt, stream=torch.cuda.current_stream().cuda_stream)
+        workload = f"strip of 8 coupled blocks {n}x{n} (SURVEY 8d config 4), all on one GPU"
     else:
+        nblocks_total = 1
         mesh = configs.single_block(n, n)                                   # TFI on the GPU (K1)
         sm = smooth.Smoother(mesh, relax_opt, stream=torch.cuda.current_stream().cuda_stream)
         workload = f"single synthetic {n}x{n} block, TFI seed, Laplace control function, fixed boundary (SURVEY 8d config 2)"
@@ -189,78 +342,100 @@ def main():
         torch.cuda.synchronize()
 
     sm.iterate(args.warmup)
-    sm.profile(True)
+    sm.profile(max(1, args.profile_every))
     barrier()
     t0 = time.perf_counter()
     st = sm.iterate(args.steps)
     barrier()
     dt = time.perf_counter() - t0
-    k2_ms, k2_launches = sm.profile_read()
-    sm.profile(False)
+    k2_ms, k2_timed, k2_launches = sm.profile_read()
+    sm.profile(0)
 
     verified = None
-    if args.verify and dist is not None:
+    if args.verify and dist is not None and coupled:
         sm.download()
-        mine = torch.from_numpy(mesh.blocks[rank].points.data.copy())
+        mine = torch.from_numpy(np.stack([mesh.blocks[b].points.data for b in owned]).copy())
         parts = [torch.empty_like(mine) for _ in range(world)] if rank == 0 else None
         if dist.get_backend() == "nccl":
             mine = mine.cuda()
             parts = [p.cuda() for p in parts] if parts else None
         dist.gather(mine, parts, dst=0)
         if rank == 0:
-            whole = configs.strip(world, n, n)
+            whole = configs.strip(nblocks_total, n, n)
             with smooth.Smoother(whole, relax_opt) as ref:
                 ref.iterate(args.warmup)
                 ref.iterate(args.steps)
                 ref.download()
-            verified = all(np.array_equal(parts[b].cpu().numpy(), whole.blocks[b].points.data) for b in range(world))
+            got = np.concatenate([p.cpu().numpy() for p in parts])
+            verified = all(np.array_equal(got[b], whole.blocks[b].points.data) for b in range(nblocks_total))
             print(f"[bench] --verify: {world} ranks vs one handle after {args.warmup}+{args.steps} sweeps: {'bit-identical' if verified else 'MISMATCH'}", file=sys.stderr)
 
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
-    nodes_total = n * n * world
+    nodes_total = n * n * nblocks_total
+    nodes_rank = n * n * len(owned)
     value = nodes_total * args.steps / dt
 
     if rank == 0:
-        k2_avg_s = (k2_ms / 1e3) / max(1, k2_launches)
-        sweeps_per_launch = st["operator_sweeps"] / max(1, k2_launches)   # one launch takes this rank's block through 1 (K2) or 2 (K2x2) sweeps
-        bytes_per_launch = BYTES_PER_NODE * n * n * sweeps_per_launch     # 32 B per node per sweep
-        achieved = bytes_per_launch / k2_avg_s / 1e9
+        k2_avg_s = (k2_ms / 1e3) / max(1, k2_timed)
+        sweeps_per_launch = st["operator_sweeps"] / max(1, k2_launches)   # one launch takes this rank's blocks through 1 (K2) or 2 (K2x2) sweeps
         fused = sweeps_per_launch > 1.5
-        traffic = None
-        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/pmc_traffic.py from rocprofv3 --pmc passes
-        if os.path.exists(tpath):
+        # what ONE launch of the dominant kernel has to move: every owned node read once and written once, however many
+        # sweeps it performs on the way (K2x2: two).  achieved / peak is therefore a true bandwidth fraction, <= 1.
+        bytes_per_launch = BYTES_PER_NODE * nodes_rank
+        achieved = bytes_per_launch / k2_avg_s / 1e9
+        traffic, traffic_src = None, None
+        tpath = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/pmc_traffic.py from separate rocprofv3 --pmc passes
+        if os.path.exists(tpath) and args.config == 2 and world == 1:
             try:
                 tj = json.load(open(tpath))
                 if tj.get("n") == n and tj.get("kernel", "k_apply") == ("k_relax2" if fused else "k_apply"):
-                    traffic = tj.get("hbm_bytes_per_launch")
+                    stale = tj.get("kernels_hash") not in (None, kernels_hash())
+                    traffic = None if stale else tj.get("hbm_bytes_per_launch")
+                    traffic_src = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of an earlier run of this command"
+                                   + (f", {tj.get('date')}" if tj.get("date") else "") + ("; STALE (kernel source changed since), dropped" if stale else ""))
             except Exception:
                 traffic = None
         out = {
-            "metric": f"nodes smoothed/sec (elliptic sweeps of the {n}^2 block) + achieved HBM GB/s",
+            "metric": f"nodes smoothed/sec (elliptic sweeps, {n}^2 blocks) + achieved HBM GB/s",
             "value": value, "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": workload, "nodes_per_gpu": n * n, "solver": "hip/relax (fused Jacobi elliptic sweep" + (", two sweeps per kernel pass)" if fused else ")"), "omega": 1.0,
-                       "residual_last": st["last_residual"], **({"verified_against_single_handle": verified} if verified is not None else {}), "whole_job_GBps_algorithmic": BYTES_PER_NODE * value / 1e9},
+            "config": {"workload": workload, "nodes_total": nodes_total, "nodes_per_gpu": nodes_rank,
+                       "solver": "hip/relax (fused Jacobi elliptic sweep" + (", two sweeps per kernel pass)" if fused else ")"), "omega": 1.0,
+                       "residual_last": st["last_residual"], **({"verified_against_single_handle": verified} if verified is not None else {}),
+                       "sweep_equiv_GBps_whole_job": BYTES_PER_NODE * value / 1e9},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
-                         "traffic": traffic,
+                         "traffic": traffic, "traffic_source": traffic_src,
                          "kernel": "k_relax2<DELTA> (K2x2: two winslow sweeps per launch)" if fused else "k_apply<RELAX,DELTA,field,laplace> (K2 winslow_apply)",
-                         "sweeps_per_launch": sweeps_per_launch, "bytes_per_launch_algorithmic": bytes_per_launch,
+                         "sweeps_per_launch": sweeps_per_launch, "bytes_per_launch": bytes_per_launch,
+                         "bytes_model": "32 B per owned node per LAUNCH: the field is read once and written once per pass (rank 0's blocks)",
+                         "sweep_equiv_GBps": BYTES_PER_NODE * nodes_rank * sweeps_per_launch / k2_avg_s / 1e9,
+                         "sweep_equiv_note": ("SURVEY 8d counts 32 B per node per SWEEP; a temporally blocked pass performs two sweeps for one read + one write, "
+                                              "so this figure may exceed the HBM peak -- it is not a bandwidth") if fused else "one sweep per launch: equals achieved",
                          "hbm_GBps_measured_traffic": (traffic / k2_avg_s / 1e9) if traffic else None,
-                         "frac_measured_traffic": (traffic / k2_avg_s / 1e9 / HBM_PEAK_GBPS) if traffic else None,
-                         "note": ("achieved = SURVEY 8d accounting (32 B per node per sweep) x 2 sweeps per launch; the launch moves the field "
-                                  "through HBM once for both sweeps (see traffic), so achieved may exceed the HBM peak; co-limited by fp64 VALU issue")
-                         if fused else "one sweep per launch",
-                         "avg_launch_us": k2_avg_s * 1e6, "launches": k2_launches,
-                         "timing": "hipEvent pairs around every K2 launch on the handle's stream, inside the timed region"},
+                         "avg_launch_us": k2_avg_s * 1e6, "launches": k2_launches, "launches_timed": k2_timed,
+                         "timing": f"hipEvent pair around every {max(1, args.profile_every)}th launch of the kernel on the handle's stream, inside the timed region"},
         }
-        if world == 1 and not args.no_solve:
+        if scaling == "strong":
+            ref1 = None
+            p1 = os.path.join(ROOT, "profiles", "config4_n1.json")
+            if os.path.exists(p1):
+                try:
+                    ref1 = json.load(open(p1)).get("value")
+                except Exception:
+                    ref1 = None
+            out["config"]["value_1gpu_stored"] = ref1
+            out["config"]["vs_1gpu"] = (value / ref1) if ref1 else None
+        if world == 1 and args.config == 2 and not args.no_solve:
             out["config"]["solve_to_1e-8"] = solve_to_tolerance(n, smooth, solver, configs)
-        if not args.no_cpu_baseline and world == 1:
-            out["cpu_baseline"] = cpu_baseline(n)
+        if not args.no_cpu_baseline and world == 1 and args.config == 2:
+            cb = cpu_baseline(n)
+            if not args.no_solve and "t106_json_as_written" in cb:
+                cb["t106_json_as_written"]["gpu_same_job"] = t106_gpu(smooth, solver, wcf)
+            out["cpu_baseline"] = cb
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None
         sys.stdout.flush()
@@ -270,6 +445,8 @@ def main():
             hooks_obj.close()
         else:
             hooks_obj.smoother.close()
+    elif sm is not None:
+        sm.close()
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()

@@ -252,11 +252,12 @@ int tm_smoother_control_function(tm_smoother* s, double* pq);
 int tm_export_soa(const double* xy /* ni*nj*2 */, uint64_t ni, uint64_t nj, double* x_out /* ni*nj */, double* y_out /* ni*nj */);
 int tm_smoother_export_soa(tm_smoother* s, uint64_t block, double* x, double* y, double* p, double* q);
 
-/* Measurement support (bench.py roofline): when enabled, every K2 `winslow_apply` launch is bracketed by a
- * pair of HIP events recorded on the handle's stream; read returns the summed elapsed milliseconds and the
- * number of launches since the last read (and resets both). */
-int tm_smoother_profile(tm_smoother* s, int enable);
-int tm_smoother_profile_read(tm_smoother* s, double* k2_ms_total, uint64_t* k2_launches);
+/* Measurement support (bench.py roofline): with every = k > 0, every k-th launch of the dominant kernel (K2
+ * `winslow_apply` / K2x2) is bracketed by a pair of HIP events recorded on the handle's stream (0 = off); read returns
+ * the summed elapsed milliseconds of the bracketed launches, how many were bracketed and how many ran since the last
+ * read (and resets all three). */
+int tm_smoother_profile(tm_smoother* s, int every);
+int tm_smoother_profile_read(tm_smoother* s, double* k2_ms_total, uint64_t* k2_launches_timed, uint64_t* k2_launches);
 
 /* ------------------------------------------------------------------ host-only planning (no GPU needed)
  * The perimeter-row table the device kernels consume, exported as CSR so it can be compared with

@@ -435,6 +435,22 @@ def time_bicgstab_iterations(xy, iters):
     return float(t), fill.value
 
 
+def time_reference_path(xy, bicg_iters, gmres_iters):
+    """Per-stage seconds of ONE outer iteration of the reference's CPU path (smooth.zig:104-154) on one (ni, nj, 2) block,
+    single thread: init, fill, BiCGStab-diagonal (x-system), ILU(0) factorisation, GMRES(30)+ILU(0) (y-system), residual +
+    copy-back.  Works on a copy of xy."""
+    w = np.array(xy, dtype=np.float64, order="C", copy=True)
+    out = np.zeros(8)
+    L = lib()
+    L.orc_time_reference_path.restype = C.c_int
+    rc = L.orc_time_reference_path(C.c_uint64(w.shape[0]), C.c_uint64(w.shape[1]), w.ctypes.data_as(_dp), C.c_uint64(bicg_iters),
+                                   C.c_uint64(gmres_iters), out.ctypes.data_as(_dp))
+    if rc != 0:
+        raise RuntimeError("orc_time_reference_path failed")
+    return {"init_s": out[0], "fill_s": out[1], "bicgstab_diag_s": out[2], "bicgstab_iterations": int(out[3]), "ilu0_factor_s": out[4],
+            "gmres30_ilu0_s": out[5], "gmres_iterations": int(out[6]), "residual_copyback_s": out[7]}
+
+
 MIRROR_RAW, MIRROR_SCALED, MIRROR_RESID, MIRROR_RELAX = 0, 1, 2, 3
 
 

@@ -242,4 +242,58 @@ double orc_time_bicgstab_iterations(uint64_t ni, uint64_t nj, double* xy, uint64
     return std::chrono::duration<double>(t3 - t2).count();
 }
 
+// Stage timings of the reference's CPU path for ONE outer iteration on one block (single thread, the reference has no threads):
+//   out[0] RowCompressedMatrixSystem2d.init (smooth.zig:309-385: pattern, row kinds, static rows)
+//   out[1] system.fill(0) (smooth.zig:923-1113)
+//   out[2] BiCGStab + diagonal preconditioner (BiCGStab.zig:279-370), out[3] = iterations executed (x-system)
+//   out[4] ILU(0) factorisation + GMRES workspace (GMRES.zig:199-298; a solve with 0 iterations)
+//   out[5] GMRES(30) + ILU(0) (GMRES.zig:300-423; factorisation included), out[6] = iterations executed (y-system)
+//   out[7] residual + copy-back (smooth.zig:112-153)
+// rtol = atol = 0 disables the stop tests, so exactly the requested iteration counts are executed and timed.
+int orc_time_reference_path(uint64_t ni, uint64_t nj, double* xy, uint64_t bicg_iters, uint64_t gmres_iters, double* out) {
+    using clk = std::chrono::steady_clock;
+    auto secs = [](clk::time_point a, clk::time_point b) { return std::chrono::duration<double>(b - a).count(); };
+    try {
+        orc_block blk{xy, ni, nj};
+        orc_mesh_desc d{&blk, 1, nullptr, 0, nullptr, 0};
+        System s;
+        auto t0 = clk::now();
+        s.init(meshFromDesc(&d), ORC_CF_LAPLACE, White{0, 0});
+        auto t1 = clk::now();
+        s.fill(0);
+        auto t2 = clk::now();
+        out[0] = secs(t0, t1);
+        out[1] = secs(t1, t2);
+        s.seedInitialGuess();
+        for (Index i = 0; i < s.dof; ++i) {   // perturbed warm start: the solvers must not return before iterating
+            s.x_new[i] += 1e-3 * std::sin(static_cast<double>(i));
+            s.y_new[i] += 1e-3 * std::cos(static_cast<double>(i));
+        }
+        const CsrView A{s.dof, s.lhs_p.data(), s.lhs_i.data(), s.lhs_values.data()};
+        s.fillXSpecific();
+        auto t3 = clk::now();
+        const SolveReport rb = bicgstab(A, s.rhs_x.data(), s.x_new.data(), diagonal, bicg_iters, 0.0, 0.0);
+        auto t4 = clk::now();
+        out[2] = secs(t3, t4);
+        out[3] = static_cast<double>(rb.iters);
+        s.fillYSpecific();
+        auto t5 = clk::now();
+        (void)gmres(A, s.rhs_y.data(), s.y_new.data(), ilu0, 30, 0, 0.0, 0.0);
+        auto t6 = clk::now();
+        const SolveReport rg = gmres(A, s.rhs_y.data(), s.y_new.data(), ilu0, 30, gmres_iters, 0.0, 0.0);
+        auto t7 = clk::now();
+        out[4] = secs(t5, t6);
+        out[5] = secs(t6, t7);
+        out[6] = static_cast<double>(rg.iters);
+        Float dx2 = 0, dy2 = 0;
+        auto t8 = clk::now();
+        (void)s.commit(&dx2, &dy2);
+        auto t9 = clk::now();
+        out[7] = secs(t8, t9);
+        return 0;
+    } catch (const std::exception& e) {
+        return -1;
+    }
+}
+
 }  // extern "C"

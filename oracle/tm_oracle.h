@@ -146,6 +146,8 @@ int orc_csr_direct(uint64_t n, const int32_t* Ap, const int32_t* Ai, const doubl
  * assembles the CSR once (fill), then runs `iters` BiCGStab iterations on the x system and
  * returns elapsed seconds of the iteration loop only (2 mat-vecs per iteration). */
 double orc_time_bicgstab_iterations(uint64_t ni, uint64_t nj, double* xy, uint64_t iters, double* fill_seconds);
+/* per-stage seconds of ONE outer iteration of the reference's CPU path on one block (see orc_api.cpp): out[8] */
+int orc_time_reference_path(uint64_t ni, uint64_t nj, double* xy, uint64_t bicg_iters, uint64_t gmres_iters, double* out);
 /* MIRROR of the device's interior-row evaluation (orc_mirror.cpp): mode 0 raw A w, 1 D^-1 A w, 2 -D^-1 A w,
  * 3 relax w + omega(-D^-1 A w); interior rows of one ni x nj block, perimeter of `out` untouched. */
 int orc_mirror_apply_block(int mode, uint64_t ni, uint64_t nj, const double* in, const double* xk, const double* pq /* or NULL */,

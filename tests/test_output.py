@@ -69,3 +69,26 @@ def test_mesh_and_smoother_write(tmp_path):
             assert np.array_equal(P, ref[:, :, 0]) and np.array_equal(Q, ref[:, :, 1])
             off += ni * nj
     assert np.abs(pq).max() > 0   # the wall control function is active
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("single", [True, False], ids=["relax", "relax2"])
+@pytest.mark.parametrize("build", [lambda: configs.single_block(70, 131, perturb=0.2), lambda: configs.strip(3, 33, 70, reverse_odd=True)], ids=["single", "strip3"])
+def test_write_between_relax_sweeps_leaves_the_handle_untouched(tmp_path, single, build):
+    # a relax handle keeps the `fixed` boundary coordinates on the perimeter of EVERY field buffer between iterate() calls
+    # (prefill_fixed); the export must not use any of them as scratch: iterate(3); write; iterate(3) == iterate(6), bit for bit
+    opt = solver.Option.hip(inner=solver.Inner.relax, single_sweep=single)
+    a, b = build(), build()
+    with smooth.Smoother(a, opt) as sm:
+        sm.iterate(6)
+        sm.download()
+    with smooth.Smoother(b, opt) as sm:
+        sm.iterate(3)
+        sm.write(os.path.join(tmp_path, "mid.xyz"))
+        sm.download()
+        for blk, (ni, nj, x, y) in zip(b.blocks, output.read_plot3d(os.path.join(tmp_path, "mid.xyz"))):
+            assert np.array_equal(x, blk.points.data[:, :, 0]) and np.array_equal(y, blk.points.data[:, :, 1])
+        sm.iterate(3)
+        sm.download()
+    for p, q in zip(a.blocks, b.blocks):
+        assert np.array_equal(p.points.data, q.points.data)

@@ -2,7 +2,7 @@
 """One-off fuzz (not collected by pytest): K2x2 against single sweeps, bit for bit, on random block shapes, sweep counts and
 relaxation factors -- exercises every combination of short / leftover row chunks and partial strip groups."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from turbomesh_amd import configs
 from turbomesh_amd.smoothing import smooth, solver

@@ -2,7 +2,7 @@
 """One-off fuzz (not collected by pytest): the multi-rank relaxation schedule (two streams, border / inside launches, direct or
 packed sends) against the single-rank run, bit for bit, on random strips, owners and sweep counts."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from tests.conftest import mesh_flat
 from tests.test_gpu_virtual_ranks import _run_ranks, SplitThreadHooks

@@ -2,7 +2,7 @@
 """One-off soak (not collected by pytest): repeated long runs of the sweep kernels must agree bit for bit with each other and with
 single sweeps -- the way the buffer_store / SGPR-offset hazard showed up (sporadic 64-byte groups) before it was understood."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy as np
 from turbomesh_amd import configs
 from turbomesh_amd.smoothing import smooth, solver

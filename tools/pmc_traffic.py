@@ -7,8 +7,11 @@ half of the bytes of a wide (16 B/lane) coalesced streaming read -> doubled; WRI
 
 usage: pmc_traffic.py <dir with FETCH_SIZE run> <dir with WRITE_SIZE run> <n> <out.json> [kernel substring = k_relax2] [sweeps per launch = 2]"""
 import csv
+import datetime
 import glob
+import hashlib
 import json
+import os
 import sys
 
 
@@ -39,6 +42,9 @@ if __name__ == "__main__":
         "hbm_bytes_per_launch": read_bytes + write_bytes, "algorithmic_bytes_per_launch": 32.0 * n * n * spl,
         "ratio_to_algorithmic": (read_bytes + write_bytes) / (32.0 * n * n * spl),
         "avg_kernel_us_under_pmc": [mean_duration_us(dfetch, kern), mean_duration_us(dwrite, kern)],
+        "kernels_hash": hashlib.sha256(open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "turbomesh_amd", "csrc",
+                                                         "tm_kernels.hip"), "rb").read()).hexdigest()[:16],
+        "date": datetime.date.today().isoformat(),
         "corrections": "FETCH_SIZE x2 (gfx950 reports half of a wide coalesced read), KiB -> bytes; separate --pmc passes",
     }
     json.dump(res, open(out, "w"), indent=1)

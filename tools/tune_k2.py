@@ -65,7 +65,7 @@ for rows, unroll, pipe in ():
     with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.bicgstab, max_inner=24, rtol=1e-30)) as sm:
         sm.profile(True)
         st = sm.iterate(1)
-        ms, k = sm.profile_read()
+        ms, k, _ = sm.profile_read()
     us = ms * 1e3 / k
     res[f"krylov_r{rows}_u{unroll}_p{pipe}"] = {"us": us, "launches": k, "iter_seconds": st["seconds"], "inner": st["inner_iterations"]}
     print(tag, "krylov apply", rows, unroll, pipe, f"{us:.1f} us avg over {k} launches; 1 Picard with {st['inner_iterations']} inner its took {st['seconds']*1e3:.1f} ms", flush=True)

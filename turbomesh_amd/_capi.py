@@ -166,7 +166,7 @@ def lib():
         L.tm_smoother_row_kinds.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.tm_smoother_control_function.argtypes = [C.c_void_p, _dp]
         L.tm_smoother_profile.argtypes = [C.c_void_p, C.c_int]
-        L.tm_smoother_profile_read.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_uint64)]
+        L.tm_smoother_profile_read.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
         L.tm_plan_build.argtypes = [C.POINTER(tm_mesh_desc), C.POINTER(tm_plan_rows)]
         L.tm_plan_free.argtypes = [C.POINTER(tm_plan_rows)]
         L.tm_plan_free.restype = None

@@ -194,18 +194,7 @@ int tm_smoother_workspace_bytes(const tm_mesh_desc* mesh, const tm_solver_opt* o
     });
 }
 void tm_smoother_destroy(tm_smoother* s) {
-    if (!s) return;
-    if (s->impl.h_S) (void)hipHostFree(s->impl.h_S);
-    if (s->impl.h_red) (void)hipHostFree(s->impl.h_red);
-    for (hipEvent_t e : s->impl.ev_start) (void)hipEventDestroy(e);
-    for (hipEvent_t e : s->impl.ev_stop) (void)hipEventDestroy(e);
-    if (s->impl.side) {
-        (void)hipStreamSynchronize(s->impl.side);
-        (void)hipEventDestroy(s->impl.ev_to_side);
-        (void)hipEventDestroy(s->impl.ev_to_main);
-        (void)hipStreamDestroy(s->impl.side);
-    }
-    delete s;
+    delete s;   // ~Smoother releases the pinned buffers, events, side stream and scratch
 }
 int tm_smoother_iterate(tm_smoother* s, uint64_t iterations, tm_stats* stats) {
     return guarded([&]() {
@@ -317,15 +306,17 @@ int tm_export_soa(const double* xy, uint64_t ni, uint64_t nj, double* x_out, dou
 int tm_smoother_profile(tm_smoother* s, int enable) {
     return guarded([&]() {
         if (!s) throw TmError(TM_E_ARG, "null handle");
-        s->impl.profile = enable != 0;
+        s->impl.profile = enable > 0 ? enable : 0;
         s->impl.ev_used = 0;
+        s->impl.prof_launches = 0;
+        s->impl.prof_timed = 0;
         return TM_OK;
     });
 }
-int tm_smoother_profile_read(tm_smoother* s, double* k2_ms_total, uint64_t* k2_launches) {
+int tm_smoother_profile_read(tm_smoother* s, double* k2_ms_total, uint64_t* k2_launches_timed, uint64_t* k2_launches) {
     return guarded([&]() {
         if (!s) throw TmError(TM_E_ARG, "null handle");
-        s->impl.profile_read(k2_ms_total, k2_launches);
+        s->impl.profile_read(k2_ms_total, k2_launches, k2_launches_timed);
         return TM_OK;
     });
 }

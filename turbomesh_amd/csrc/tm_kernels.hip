@@ -584,7 +584,7 @@ __device__ __forceinline__ void relax2_strip_inside(const Relax2Block& a, const 
             S[A2] = make_row(relax_row<W1>(A[A0], A[A1], A[A2], a.omega, d1));
             const double2 o = relax_row<W1>(S[A0], S[A1], S[A2], a.omega, d2);
             // the row offset travels in the VGPR offset: with an SGPR soffset the 128-bit store data was observed to be picked
-            // up late (lanes 12..15 of each 16 saw a later VALU result) -- measured on gfx950, tests/dbg_fused.py
+            // up late (lanes 12..15 of each 16 saw a later VALU result) -- measured on gfx950, tools/dev/dbg_fused.py
 #if defined(TM_R2_DIAG) && (TM_R2_DIAG & 2)
             acc[2] += o.x + o.y;   // diagnostic build: no stores
 #else

@@ -110,6 +110,21 @@ static void connection_data_check(const Topology& t, const tm_mesh_desc* m, cons
 
 void Smoother::sync() { HIPCHK(hipStreamSynchronize(stream)); }
 
+// Everything the handle owns outside the arena; also runs when create() throws half-way (pinned buffers already allocated).
+Smoother::~Smoother() {
+    if (h_S) (void)hipHostFree(h_S);
+    if (h_red) (void)hipHostFree(h_red);
+    for (hipEvent_t e : ev_start) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ev_stop) (void)hipEventDestroy(e);
+    if (side) {
+        (void)hipStreamSynchronize(side);
+        (void)hipEventDestroy(ev_to_side);
+        (void)hipEventDestroy(ev_to_main);
+        (void)hipStreamDestroy(side);
+    }
+    if (export_buf) (void)hipFree(export_buf);
+}
+
 // ------------------------------------------------------------------ create
 void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm_control_fn* c, const tm_comm_hooks* h, void* strm,
                       bool measure) {
@@ -430,6 +445,14 @@ void Smoother::profiled(const std::function<void()>& launch, bool counts) {
         launch();
         return;
     }
+    // sampling: only every profile-th pass carries event pairs (two extra packets on the stream per pair).  The parts of a
+    // split pass (inside: counts == false, then border: counts == true) see the same prof_launches, hence the same decision.
+    const bool prof_sample = (prof_launches % static_cast<uint64_t>(profile)) == 0;
+    if (!prof_sample) {
+        launch();
+        if (counts) prof_launches += 1;
+        return;
+    }
     if (ev_used == ev_start.size()) {
         hipEvent_t e0, e1;
         HIPCHK(hipEventCreate(&e0));
@@ -441,7 +464,10 @@ void Smoother::profiled(const std::function<void()>& launch, bool counts) {
     launch();
     HIPCHK(hipEventRecord(ev_stop[ev_used], stream));
     ev_used += 1;
-    if (counts) prof_launches += 1;
+    if (counts) {
+        prof_launches += 1;
+        prof_timed += 1;
+    }
 }
 
 void Smoother::apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega, int step) {
@@ -773,7 +799,7 @@ bool Smoother::iterate_until(uint64_t max_iterations, double tol, tm_stats* stat
     return reached;
 }
 
-void Smoother::profile_read(double* ms_total, uint64_t* launches) {
+void Smoother::profile_read(double* ms_total, uint64_t* launches, uint64_t* timed) {
     sync();
     double total = 0.0;
     for (size_t k = 0; k < ev_used; ++k) {
@@ -783,8 +809,10 @@ void Smoother::profile_read(double* ms_total, uint64_t* launches) {
     }
     if (ms_total) *ms_total = total;
     if (launches) *launches = prof_launches;
+    if (timed) *timed = prof_timed;
     ev_used = 0;
     prof_launches = 0;
+    prof_timed = 0;
 }
 
 // ------------------------------------------------------------------ introspection
@@ -834,7 +862,16 @@ void Smoother::export_soa_host(int64_t block, double* x, double* y, double* p, d
     const int64_t ls = lp.local_start[it - lp.owned_blocks.begin()];
     const int bi = static_cast<int>(topo.ni[block]), bj = static_cast<int>(topo.nj[block]);
     const size_t n = static_cast<size_t>(bi) * bj;
-    double* planes = reinterpret_cast<double*>(U);   // the ping-pong vector is free between iterate() calls: n double2 = two planes
+    // own scratch (two planes of the largest block exported so far): on a relax handle every field buffer, U included, carries the
+    // `fixed` boundary coordinates on its perimeter between iterate() calls (prefill_fixed) -- none of them is free to scribble on
+    if (export_bytes < sizeof(double) * 2 * n) {
+        if (export_buf) (void)hipFree(export_buf);
+        export_buf = nullptr;
+        export_bytes = 0;
+        if (hipMalloc(&export_buf, sizeof(double) * 2 * n) != hipSuccess) throw TmError(TM_E_MEMORY, "hipMalloc failed (export planes)");
+        export_bytes = sizeof(double) * 2 * n;
+    }
+    double* planes = static_cast<double*>(export_buf);
     HIPCHK(launch_soa_planes(X + ls, planes, planes + n, bi, bj, stream));
     HIPCHK(hipMemcpyAsync(x, planes, sizeof(double) * n, hipMemcpyDeviceToHost, stream));
     HIPCHK(hipMemcpyAsync(y, planes + n, sizeof(double) * n, hipMemcpyDeviceToHost, stream));

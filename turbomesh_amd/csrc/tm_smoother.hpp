@@ -38,6 +38,10 @@ class DeviceArena {
 };
 
 struct Smoother {
+    Smoother() = default;
+    ~Smoother();
+    Smoother(const Smoother&) = delete;
+    Smoother& operator=(const Smoother&) = delete;
     Topology topo;
     std::vector<PlanRow> all_rows;
     LocalPlan lp;
@@ -92,11 +96,12 @@ struct Smoother {
     ConnShifts white_le{};
     uint64_t outer_done = 0;
     // measurement: HIP event pairs around K2 launches
-    bool profile = false;
+    int profile = 0;                // 0 = off, k > 0 = every k-th launch of the dominant kernel is bracketed
     std::vector<hipEvent_t> ev_start, ev_stop;
     size_t ev_used = 0;
     uint64_t prof_launches = 0;     // event pairs that count as a launch of the dominant kernel (the parts of a split K2x2 pass count once)
-    void profile_read(double* ms_total, uint64_t* launches);
+    uint64_t prof_timed = 0;        // ... of which carried an event pair
+    void profile_read(double* ms_total, uint64_t* launches, uint64_t* timed);
 
     void create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm_control_fn* c, const tm_comm_hooks* h, void* strm,
                 bool measure);
@@ -109,6 +114,8 @@ struct Smoother {
     void rhs_host(double* rhs_xy);
     void control_function_host(double* pq);
     void export_soa_host(int64_t block, double* x, double* y, double* p, double* q);
+    void* export_buf = nullptr;     // scratch planes of export_soa_host (hipMalloc, grown on demand)
+    size_t export_bytes = 0;
 
     // building blocks
     void exchange(double2* vec, hipStream_t on = nullptr);   // start (and, without a split hook, finish) the halo exchange of `vec`; on = the handle's stream unless given

@@ -254,16 +254,29 @@ class RcclHooks:
     rank 0's ncclUniqueId to the other ranks; after that no Python runs inside a sweep (a batch_isend_irecv per exchange
     costs 50-70 us of host time, tools/ubench/p2p_host_cost.py -- more than half of a two-sweep pass of a 4096^2 block)."""
 
-    def __init__(self, mesh, owner, rank, world, option=None, control=None, group=None, device=None):
+    @staticmethod
+    def _librccl_path():
         import os
 
+        import torch
+
+        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        return path.encode() if os.path.exists(path) else None
+
+    @staticmethod
+    def precheck():
+        """Everything a rank can check ALONE before the first collective call: librccl loads, its symbols resolve and a
+        unique id can be made.  Ranks vote on this (all_reduce MIN) before any of them enters ncclCommInitRank."""
+        uid = (C.c_ubyte * 128)()
+        _capi.check(_capi.lib().tm_rccl_unique_id(RcclHooks._librccl_path(), uid))
+
+    def __init__(self, mesh, owner, rank, world, option=None, control=None, group=None, device=None):
         import torch
         import torch.distributed as dist
 
         self.rank, self.world = rank, world
         L = _capi.lib()
-        path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        self._path = path.encode() if os.path.exists(path) else None
+        self._path = self._librccl_path()
         device = device or torch.device("cuda", torch.cuda.current_device())
         uid = (C.c_ubyte * 128)()
         if rank == 0:

@@ -107,15 +107,17 @@ class Smoother:
         _capi.check(_capi.lib().tm_smoother_row_kinds(self._h, out.ctypes.data_as(C.POINTER(C.c_int32))))
         return out
 
-    def profile(self, enable=True):
-        _capi.check(_capi.lib().tm_smoother_profile(self._h, 1 if enable else 0))
+    def profile(self, every=1):
+        """Bracket every `every`-th launch of the dominant kernel with a hipEvent pair (0 / False = off)."""
+        _capi.check(_capi.lib().tm_smoother_profile(self._h, int(every)))
 
     def profile_read(self):
-        """(milliseconds summed over K2 launches, number of K2 launches) since the last read."""
+        """(milliseconds summed over the bracketed launches, how many were bracketed, launches in total) since the last read."""
         ms = C.c_double(0)
+        timed = C.c_uint64(0)
         n = C.c_uint64(0)
-        _capi.check(_capi.lib().tm_smoother_profile_read(self._h, C.byref(ms), C.byref(n)))
-        return ms.value, int(n.value)
+        _capi.check(_capi.lib().tm_smoother_profile_read(self._h, C.byref(ms), C.byref(timed), C.byref(n)))
+        return ms.value, int(timed.value), int(n.value)
 
     def control_function(self):
         out = np.empty((self.dof, 2))
