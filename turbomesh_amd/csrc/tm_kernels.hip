@@ -1455,6 +1455,13 @@ __device__ __forceinline__ double2 d2_scale(double s, double2 v) { return make_d
 // the scalings are the identity and the fix-up passes the value through, so ONE reciprocal refinement serves both quotients
 // and each costs mul + 2 fma more: the same bits (see recip_diag).  Anything else takes the plain divisions (wave-uniform).
 __device__ __forceinline__ void div_pair(double nu, double nv, double du, double dv, double& u, double& v) {
+    // Opposite edges with the same clustering (s2 == s1 or t2 == t1: every uniform block, BASELINE configs 2, 4, 5) make both
+    // denominators exactly 1 - 0 = 1.0, and x / 1.0 == x bit for bit for every x: no division at all (wave-uniform test).
+    if (__builtin_amdgcn_ballot_w64(!((du == 1.0) && (dv == 1.0))) == 0) {
+        u = nu;
+        v = nv;
+        return;
+    }
     const double au = fabs(nu), av = fabs(nv), ad = fabs(du);
     const bool plain = (du == dv) && (ad >= 0x1p-500) && (ad <= 0x1p500) && (au == 0.0 || (au >= 0x1p-500 && au <= 0x1p500)) &&
                        (av == 0.0 || (av >= 0x1p-500 && av <= 0x1p500));
@@ -1474,23 +1481,36 @@ __device__ __forceinline__ void div_pair(double nu, double nv, double du, double
     v = nv / dv;
 }
 
+constexpr int TFI_ROWS = 8;   // rows per thread: the column's edge data (t1, t2, x_0j, x_nj) is loaded once per 8 nodes
 __global__ __launch_bounds__(256) void k_tfi_block(double2* __restrict__ xy, int n, int m, const double2* __restrict__ x_i_min,
                                                    const double2* __restrict__ x_i_max, const double2* __restrict__ x_j_min,
                                                    const double2* __restrict__ x_j_max, const double* __restrict__ s1,
                                                    const double* __restrict__ s2, const double* __restrict__ t1,
                                                    const double* __restrict__ t2) {
     const int j = blockIdx.x * 64 + threadIdx.x;
-    const int ib = (blockIdx.y * 4 + threadIdx.y) * 4;   // 4 rows per thread: edge-j data reused from registers
-    if (j >= m) return;
+    // a wave = 64 consecutive columns of ONE group of rows: the row index is wave-uniform, so the row's edge data (s1, s2, x_i0,
+    // x_im) comes through the scalar cache and all of a thread's rows are requested before the first is needed
+    const int ib = __builtin_amdgcn_readfirstlane(static_cast<int>(blockIdx.y * 4 + threadIdx.y) * TFI_ROWS);
+    if (j >= m || ib >= n) return;
     const double2 x_0_0 = x_i_min[0], x_n_0 = x_i_min[n - 1], x_0_m = x_j_min[m - 1], x_n_m = x_i_max[n - 1];
     const double t1_j = t1[j], t2_j = t2[j];
     const double2 x_0_j = x_j_min[j], x_n_j = x_j_max[j];
+    double s1v[TFI_ROWS], s2v[TFI_ROWS];
+    double2 xi0[TFI_ROWS], xim[TFI_ROWS];
 #pragma unroll
-    for (int k = 0; k < 4; ++k) {
-        const int i = ib + k;
-        if (i >= n) break;
-        const double s1_i = s1[i], s2_i = s2[i];
-        const double2 x_i_0 = x_i_min[i], x_i_m = x_i_max[i];
+    for (int k = 0; k < TFI_ROWS; ++k) {
+        const int i = min(ib + k, n - 1);
+        s1v[k] = s1[i];
+        s2v[k] = s2[i];
+        xi0[k] = x_i_min[i];
+        xim[k] = x_i_max[i];
+    }
+    double2* dst = xy + static_cast<size_t>(ib) * m + j;
+#pragma unroll
+    for (int k = 0; k < TFI_ROWS; ++k) {
+        if (ib + k >= n) break;   // scalar
+        const double s1_i = s1v[k], s2_i = s2v[k];
+        const double2 x_i_0 = xi0[k], x_i_m = xim[k];
         // tfi.zig:185-186: u = nu / (1 - (s2-s1)(t2-t1)), v = nv / (1 - (t2-t1)(s2-s1)) -- the two denominators are the same
         // number (one IEEE product, either order); both quotients correctly rounded like the reference's divisions
         double u, v;
@@ -1507,12 +1527,12 @@ __global__ __launch_bounds__(256) void k_tfi_block(double2* __restrict__ xy, int
         d2v ov;   // write-only stream of the whole block: non-temporal like the sweep kernels' stores
         ov.x = o.x;
         ov.y = o.y;
-        __builtin_nontemporal_store(ov, reinterpret_cast<d2v*>(xy + static_cast<size_t>(i) * m + j));
+        __builtin_nontemporal_store(ov, reinterpret_cast<d2v*>(dst + static_cast<size_t>(k) * m));
     }
 }
 hipError_t launch_tfi_block(double2* xy, int ni, int nj, const double2* a, const double2* b, const double2* c, const double2* d,
                             const double* s1, const double* s2, const double* t1, const double* t2, hipStream_t st) {
-    const dim3 block(64, 4), grid((nj + 63) / 64, (ni + 15) / 16);
+    const dim3 block(64, 4), grid((nj + 63) / 64, (ni + 4 * TFI_ROWS - 1) / (4 * TFI_ROWS));
     hipLaunchKernelGGL(k_tfi_block, grid, block, 0, st, xy, ni, nj, a, b, c, d, s1, s2, t1, t2);
     return hipGetLastError();
 }
