@@ -277,9 +277,13 @@ typedef struct tm_plan_rows {
 int tm_plan_build(const tm_mesh_desc* mesh, tm_plan_rows* out);
 void tm_plan_free(tm_plan_rows* rows);
 
-/* Rank-local view of a partitioned mesh (host-only): which rows a rank owns, which remote rows it reads
+/* Rank-local view of a partitioned mesh (host-only): which rows a rank owns, which remote rows it keeps copies of
  * (ghost rows, appended after the owned rows in every rank-local vector) and the halo exchange lists.
- * Every rank computes the same tables from the global topology, so no set-up communication is needed. */
+ * Every rank computes the same tables from the global topology, so no set-up communication is needed.
+ * The halo is two rows deep: the remote rows the rank's perimeter rows read (the reference couples blocks through
+ * smooth.zig:618-693, 994-1105: interface row, first interior row of either side, junction neighbours) -- listed in
+ * ghost_row_* with their own columns -- AND the remote rows those read, so that a rank can evaluate the former one sweep
+ * ahead and a PAIR of relaxation sweeps needs one exchange. */
 typedef struct tm_plan_local_info {
     int64_t n_owned, n_ghost, n_send;
     int32_t npeers, nowned_blocks;
@@ -297,6 +301,10 @@ typedef struct tm_plan_local_info {
     int32_t direct_send;     /* 1: every peer's send list is one ascending run of local rows -- a handle then sends
                                 straight from the vector (tm_smoother_exchange_plan offsets = send_first), no pack kernel */
     int32_t _pad;
+    int64_t n_ghost_rows;    /* ghost rows this rank can evaluate itself (the depth-1 part of the halo)                 */
+    int64_t* ghost_row_gid;  /* [n_ghost_rows]                                                                           */
+    int32_t* ghost_row_kind; /* [n_ghost_rows] BlockBoundaryPointKind of the row, or 5 = interior node of the remote block */
+    int64_t* ghost_row_cols; /* [n_ghost_rows * 9] global ids of its columns, -1 padded                                  */
 } tm_plan_local_info;
 int tm_plan_local(const tm_mesh_desc* mesh, const int32_t* owner, int32_t rank, int32_t nranks, tm_plan_local_info* out);
 void tm_plan_local_free(tm_plan_local_info* info);

@@ -77,6 +77,10 @@ def _worker(rank, world, port, kind, owner, q):
             for c, a in zip(r.indices, r.data):
                 acc = acc + a * local[g2l[int(c)]]
             assert np.allclose(acc, ref[g], rtol=1e-13, atol=1e-13)
+        # depth-2 halo: every column of every ghost row this rank evaluates itself is owned or ghost as well
+        for gid, cols in zip(plan["ghost_row_gid"], plan["ghost_row_cols"]):
+            assert int(gid) in g2l and g2l[int(gid)] >= n_owned
+            assert all(int(c) in g2l for c in cols if c >= 0), f"rank {rank}: ghost row {gid} reads a row that is neither owned nor ghost"
         # partition check + all-reduce
         t = torch.tensor([float(n_owned), float(len(mine)), 1.0, float(rank)], dtype=torch.float64)
         x.allreduce(t)
@@ -125,16 +129,24 @@ def test_strip_for_rank_matches_full_strip():
 
 
 def test_direct_send_plans():
-    # a strip's interfaces run along whole block rows: each peer's send list is ONE run of local rows (one row per direction), so
-    # a handle sends straight from its vector; a 2 x 2 arrangement has column interfaces (strided rows) and keeps the pack kernel
+    # a strip's interfaces run along whole block rows: each peer's send list is ONE run of local rows, so a handle sends straight
+    # from its vector; a 2 x 2 arrangement has column interfaces (strided rows) and keeps the pack kernel.  Depth-2 halo: the
+    # solved side of an interface (ranges[0], the lower block) sends its interface row + first interior row -- what the upper block
+    # needs to evaluate that `smoothed` interface row itself --, the slaved side (ranges[1]) its interface row + TWO interior rows
+    # -- what the lower block needs to evaluate the upper block's first interior row (smooth.zig:1029-1032, 1071-1084)
     strip = configs.strip(4, 9, 12, tfi=oracle_tfi, reverse_odd=True)
     for rank in range(4):
         p = tmd.local_plan(strip, [0, 1, 2, 3], rank, 4)
         assert p["direct_send"] and len(p["peer_rank"]) == (1 if rank in (0, 3) else 2)
         for k in range(len(p["peer_rank"])):
             o, c = int(p["send_offset"][k]), int(p["send_count"][k])
-            assert c == 12                                                  # exactly one block row per neighbour
+            assert c == (3 * 12 if p["peer_rank"][k] < rank else 2 * 12)
             assert np.array_equal(p["send_ids"][o:o + c], p["send_first"][k] + np.arange(c))
+        # the depth-1 part of the halo, with the rows' own definitions: the neighbour's first interior row (interior nodes + its two
+        # wall nodes) seen from below, its interface row seen from above
+        kinds = np.bincount(p["ghost_row_kind"], minlength=6)
+        below, above = rank < 3, rank > 0
+        assert kinds[5] == (10 if below else 0) and kinds[1] == (10 if above else 0) and kinds[0] == (2 if below else 0) + (2 if above else 0)
     grid = configs.two_by_two(8, 9, tfi=oracle_tfi)
     assert not any(tmd.local_plan(grid, [0, 1, 2, 3], r, 4)["direct_send"] for r in range(4))
     assert not tmd.local_plan(strip, [0, 0, 0, 0], 0, 1)["direct_send"]   # nobody to send to

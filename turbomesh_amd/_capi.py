@@ -94,7 +94,9 @@ class tm_plan_local_info(C.Structure):
                 ("owned_blocks", C.POINTER(C.c_int64)), ("local_start", C.POINTER(C.c_int64)), ("ghost_gid", C.POINTER(C.c_int64)),
                 ("send_ids", C.POINTER(C.c_int32)), ("send_gid", C.POINTER(C.c_int64)), ("peer_rank", C.POINTER(C.c_int32)),
                 ("send_offset", C.POINTER(C.c_int64)), ("send_count", C.POINTER(C.c_int64)), ("recv_offset", C.POINTER(C.c_int64)),
-                ("recv_count", C.POINTER(C.c_int64)), ("send_first", C.POINTER(C.c_int64)), ("direct_send", C.c_int32), ("_pad", C.c_int32)]
+                ("recv_count", C.POINTER(C.c_int64)), ("send_first", C.POINTER(C.c_int64)), ("direct_send", C.c_int32), ("_pad", C.c_int32),
+                ("n_ghost_rows", C.c_int64), ("ghost_row_gid", C.POINTER(C.c_int64)), ("ghost_row_kind", C.POINTER(C.c_int32)),
+                ("ghost_row_cols", C.POINTER(C.c_int64))]
 
 
 # every symbol include/tm_hip.h declares (checked by tests/test_capi_symbols.py)

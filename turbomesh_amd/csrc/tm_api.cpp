@@ -370,6 +370,17 @@ int tm_plan_local(const tm_mesh_desc* mesh, const int32_t* owner, int32_t rank, 
         out->recv_count = dup(lp.recv_cnt);
         out->send_first = dup(lp.send_first);
         out->direct_send = lp.direct_send ? 1 : 0;
+        std::vector<int64_t> gg, gc;
+        std::vector<int32_t> gk;
+        for (const PlanRow& g : lp.ghost_rows) {
+            gg.push_back(g.gid);
+            gk.push_back(g.kind);
+            for (int q = 0; q < 9; ++q) gc.push_back(q < g.ncols ? g.col[q] : -1);
+        }
+        out->n_ghost_rows = static_cast<int64_t>(gg.size());
+        out->ghost_row_gid = dup(gg);
+        out->ghost_row_kind = dup(gk);
+        out->ghost_row_cols = dup(gc);
         return TM_OK;
     });
 }
@@ -386,6 +397,9 @@ void tm_plan_local_free(tm_plan_local_info* i) {
     std::free(i->send_count);
     std::free(i->recv_offset);
     std::free(i->recv_count);
+    std::free(i->ghost_row_gid);
+    std::free(i->ghost_row_kind);
+    std::free(i->ghost_row_cols);
     std::memset(i, 0, sizeof(*i));
 }
 

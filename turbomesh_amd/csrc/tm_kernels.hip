@@ -936,6 +936,17 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const d
         const int nc = e.ncols[r];
         const int self = e.self[r];
         double sx = 0.0, sy = 0.0, rhs_x, rhs_y, diag_x, diag_y;
+        if (MODE == MODE_RELAX && kind == 5) {
+            // interior node of a REMOTE block, evaluated here as a ghost row (depth-2 halo): K2's own arithmetic on the gathered
+            // 3 x 3 neighbourhood (columns in (i-1,j-1) ... (i+1,j+1) order), bit-identical to what the owner's K2 / K2x2 stores
+            const size_t n = e.nrows;
+            const double2 ml = in[e.cols[r]], mc = in[e.cols[n + r]], mr = in[e.cols[2 * n + r]];
+            const double2 cl = in[e.cols[3 * n + r]], cc = in[e.cols[4 * n + r]], cr = in[e.cols[5 * n + r]];
+            const double2 pl = in[e.cols[6 * n + r]], pc = in[e.cols[7 * n + r]], pr = in[e.cols[8 * n + r]];
+            const double2 c_e = sub2(cr, cl);
+            double2 delta;
+            out[row] = winslow_row<MODE_RELAX, false>(mc, sub2(mr, ml), cc, c_e, add2(cr, cl), pc, sub2(pr, pl), sub2(pc, mc), c_e, 0.0, 0.0, omega, delta);
+        } else {
         if (kind == 1 /* smoothed */) {
             const double2 im1_j = xk[e.metric[r]], ip1_j = xk[e.metric[e.nrows + r]], i_jm1 = xk[e.metric[2 * static_cast<size_t>(e.nrows) + r]];
             double2 i_jp1 = xk[e.metric[3 * static_cast<size_t>(e.nrows) + r]];
@@ -986,6 +997,11 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const d
             rhs_y = e.rhs[2 * r + 1];
         }
         const double2 w_self = in[row];
+        // ghost copies of rows whose right-hand side is the node's own boundary coordinate (fixed rows, the x-system of sliding
+        // rows): that coordinate IS the row's current value -- such a row reproduces it in every sweep
+        const int fl = e.flags[r];
+        if (fl & 4) rhs_x = w_self.x;
+        if (fl & 8) rhs_y = w_self.y;
         // constraint rows are enforced exactly in a relaxation sweep (omega = 1); smoothed rows relax like interior rows
         const double om = (kind == 1) ? omega : 1.0;
         double2 o;
@@ -993,6 +1009,7 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const d
         o.y = row_out<MODE>(sy, rhs_y, diag_y, w_self.y, om);
         out[row] = o;
         accumulate<DOT>(acc, w_self, o, (DOT == DOT_AUX || DOT == DOT_AUX2) ? aux[row] : ((DOT == DOT_DELTA) ? make_double2(o.x - w_self.x, o.y - w_self.y) : o));
+        }
     }
     if (DOT != DOT_NONE) block_partials<EDGE_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }

@@ -518,6 +518,40 @@ LocalPlan build_local_plan(const Topology& t, const std::vector<PlanRow>& all_ro
         std::sort(v.begin(), v.end());
         v.erase(std::unique(v.begin(), v.end()), v.end());
     }
+    // depth 2: the definition of every depth-1 ghost row, and the remote rows IT reads
+    auto row_def = [&](int64_t gid) {
+        const auto it = std::lower_bound(all_rows.begin(), all_rows.end(), gid, [](const PlanRow& a, int64_t g) { return a.gid < g; });
+        if (it != all_rows.end() && it->gid == gid) return *it;
+        int64_t b = nb - 1;
+        while (gid < t.start[b]) --b;
+        const int64_t nj = t.nj[b];
+        PlanRow r{};
+        r.gid = gid;
+        r.kind = KIND_INTERIOR;
+        r.ncols = 9;
+        r.self = 4;
+        int q = 0;
+        for (int64_t di = -1; di <= 1; ++di)
+            for (int64_t dj = -1; dj <= 1; ++dj) r.col[q++] = gid + di * nj + dj;
+        return r;
+    };
+    std::vector<std::vector<std::pair<int32_t, int64_t>>> need2 = need;
+    for (int r = 0; r < nranks; ++r) {
+        for (const auto& pr : need[r]) {
+            const PlanRow def = row_def(pr.second);
+            auto touch = [&](int64_t gid) {
+                const int32_t o = owner_of_gid(gid);
+                if (o != r) need2[r].emplace_back(o, gid);
+            };
+            for (int k = 0; k < def.ncols; ++k) touch(def.col[k]);
+            if (def.kind == KIND_SMOOTHED)
+                for (int k = 0; k < 4; ++k) touch(def.metric[k]);
+            if (r == rank) lp.ghost_rows.push_back(def);
+        }
+        std::sort(need2[r].begin(), need2[r].end());
+        need2[r].erase(std::unique(need2[r].begin(), need2[r].end()), need2[r].end());
+    }
+    need.swap(need2);
     for (const auto& pr : need[rank]) {
         lp.ghost_index[pr.second] = static_cast<int64_t>(lp.ghost_gid.size());
         lp.ghost_gid.push_back(pr.second);

@@ -21,7 +21,12 @@ struct PlanError : std::runtime_error {
 
 enum Side : uint32_t { SIDE_I_MIN = 0, SIDE_I_MAX = 1, SIDE_J_MIN = 2, SIDE_J_MAX = 3 };
 // BlockBoundaryPointKind, smooth.zig:1168-1174
-enum RowKind : int8_t { KIND_FIXED = 0, KIND_SMOOTHED = 1, KIND_CONNECTED = 2, KIND_JUNCTION = 3, KIND_SLIDING = 4 };
+enum RowKind : int8_t {
+    KIND_FIXED = 0, KIND_SMOOTHED = 1, KIND_CONNECTED = 2, KIND_JUNCTION = 3, KIND_SLIDING = 4,
+    // not a reference kind: an INTERIOR node of a remote block (matrix-free 9-point row, K2's arithmetic) that a rank evaluates
+    // redundantly as a ghost row (LocalPlan::ghost_rows); col[] = (i-1,j-1) (i-1,j) (i-1,j+1) (i,j-1) (i,j) (i,j+1) (i+1,j-1) (i+1,j) (i+1,j+1)
+    KIND_INTERIOR = 5
+};
 
 struct TopoRange {
     int64_t block;
@@ -83,6 +88,11 @@ struct LocalPlan {
     int64_t n_owned = 0;                    // owned rows
     std::vector<int64_t> ghost_gid;         // ghost rows (sorted by owner rank, then gid); local id = n_owned + k
     std::vector<PlanRow> rows;              // owned perimeter rows (global ids inside)
+    // Depth-2 halo.  The remote rows my perimeter rows read (the depth-1 ghost set) can be EVALUATED here, one sweep ahead, from the
+    // previous field: ghost_rows holds their definitions (perimeter rows of the neighbour as they stand in its table, or
+    // KIND_INTERIOR rows for its first-interior nodes), and the ghost set above also contains every remote row THOSE read.  A pair of
+    // relaxation sweeps then needs ONE exchange: X^k of the depth-2 set travels, the depth-1 rows of X^(k+1) are recomputed.
+    std::vector<PlanRow> ghost_rows;
     // halo exchange: for peer k, my rows send_ids[send_off[k] .. +send_cnt[k]) (local ids) go to peer_rank[k];
     // its rows land in my ghost segment at [recv_off[k], +recv_cnt[k])
     std::vector<int32_t> peer_rank;

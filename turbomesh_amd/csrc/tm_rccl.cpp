@@ -13,6 +13,7 @@
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
 
+#include <cstdlib>
 #include <cstring>
 #include <memory>
 #include <mutex>
@@ -85,7 +86,12 @@ using namespace tmh;
 struct tm_rccl_comm {
     NcclComm comm = nullptr;
     int32_t rank = 0, nranks = 1;
-    hipStream_t stream = nullptr;       // transfers run here, beside the handle's compute stream
+    // Where the transfers are enqueued.  Default: on the stream the handle names for the call -- the chain of a sweep pair
+    // (perimeter rows -> exchange -> perimeter rows -> border workgroups) is bound by dependency latency, and a hop to another
+    // queue and back costs two event waits of ~13 us each on this part.  TM_RCCL_OWN_STREAM=1 selects the other form: an own
+    // high-priority stream fenced with two events, which lets a Krylov-path exchange run beside the interior-row kernel.
+    bool own_stream = false;
+    hipStream_t stream = nullptr;
     hipEvent_t ready = nullptr, done = nullptr;
     // exchange pattern of the partition given to tm_rccl_hooks (rows are double2)
     std::vector<int32_t> owner, peer;
@@ -99,17 +105,20 @@ int rccl_exchange(void* ctx, const double* send_buf, double* recv_buf, void* str
     try {
         if (c->peer.empty()) return 0;
         hipStream_t s = static_cast<hipStream_t>(stream);
-        HIPCHK(hipEventRecord(c->ready, s));   // the pack kernel has filled send_buf
-        HIPCHK(hipStreamWaitEvent(c->stream, c->ready, 0));
+        hipStream_t xs = c->own_stream ? c->stream : s;
+        if (c->own_stream) {
+            HIPCHK(hipEventRecord(c->ready, s));   // the pack kernel has filled send_buf
+            HIPCHK(hipStreamWaitEvent(c->stream, c->ready, 0));
+        }
         nccl_check(g_rccl.GroupStart(), "ncclGroupStart");
         for (size_t k = 0; k < c->peer.size(); ++k) {
             if (c->recv_cnt[k])
-                nccl_check(g_rccl.Recv(recv_buf + 2 * c->recv_off[k], static_cast<size_t>(2 * c->recv_cnt[k]), NCCL_FLOAT64, c->peer[k], c->comm, c->stream), "ncclRecv");
+                nccl_check(g_rccl.Recv(recv_buf + 2 * c->recv_off[k], static_cast<size_t>(2 * c->recv_cnt[k]), NCCL_FLOAT64, c->peer[k], c->comm, xs), "ncclRecv");
             if (c->send_cnt[k])
-                nccl_check(g_rccl.Send(send_buf + 2 * c->send_off[k], static_cast<size_t>(2 * c->send_cnt[k]), NCCL_FLOAT64, c->peer[k], c->comm, c->stream), "ncclSend");
+                nccl_check(g_rccl.Send(send_buf + 2 * c->send_off[k], static_cast<size_t>(2 * c->send_cnt[k]), NCCL_FLOAT64, c->peer[k], c->comm, xs), "ncclSend");
         }
         nccl_check(g_rccl.GroupEnd(), "ncclGroupEnd");
-        HIPCHK(hipEventRecord(c->done, c->stream));
+        if (c->own_stream) HIPCHK(hipEventRecord(c->done, c->stream));
         return 0;
     } catch (const std::exception& e) {
         g_last_error = e.what();
@@ -119,7 +128,7 @@ int rccl_exchange(void* ctx, const double* send_buf, double* recv_buf, void* str
 
 int rccl_exchange_wait(void* ctx, void* stream) {
     tm_rccl_comm* c = static_cast<tm_rccl_comm*>(ctx);
-    if (c->peer.empty()) return 0;
+    if (c->peer.empty() || !c->own_stream) return 0;   // enqueued on `stream` itself: already ordered
     return hipStreamWaitEvent(static_cast<hipStream_t>(stream), c->done, 0) == hipSuccess ? 0 : 1;
 }
 
@@ -127,8 +136,12 @@ int rccl_allreduce(void* ctx, double* buf, int32_t n, void* stream) {
     tm_rccl_comm* c = static_cast<tm_rccl_comm*>(ctx);
     try {
         if (c->nranks == 1) return 0;
-        // on the transfer stream too: operations of one communicator stay in one queue
         hipStream_t s = static_cast<hipStream_t>(stream);
+        if (!c->own_stream) {
+            nccl_check(g_rccl.AllReduce(buf, buf, static_cast<size_t>(n), NCCL_FLOAT64, NCCL_SUM, c->comm, s), "ncclAllReduce");
+            return 0;
+        }
+        // on the transfer stream too: operations of one communicator stay in one queue
         HIPCHK(hipEventRecord(c->ready, s));
         HIPCHK(hipStreamWaitEvent(c->stream, c->ready, 0));
         nccl_check(g_rccl.AllReduce(buf, buf, static_cast<size_t>(n), NCCL_FLOAT64, NCCL_SUM, c->comm, c->stream), "ncclAllReduce");
@@ -166,6 +179,8 @@ int tm_rccl_comm_create(const char* librccl_path, const void* id, int32_t rank, 
         NcclUniqueId uid;
         std::memcpy(&uid, id, sizeof(uid));
         nccl_check(api.CommInitRank(&c->comm, nranks, uid, rank), "ncclCommInitRank");
+        const char* own = std::getenv("TM_RCCL_OWN_STREAM");
+        c->own_stream = own && own[0] == '1';
         int least = 0, greatest = 0;   // transfers are tiny and latency-critical
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPCHK(hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, greatest));

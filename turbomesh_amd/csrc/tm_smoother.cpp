@@ -120,6 +120,8 @@ Smoother::~Smoother() {
         (void)hipStreamSynchronize(side);
         (void)hipEventDestroy(ev_to_side);
         (void)hipEventDestroy(ev_to_main);
+        (void)hipEventDestroy(ev_inside[0]);
+        (void)hipEventDestroy(ev_inside[1]);
         (void)hipStreamDestroy(side);
     }
     if (export_buf) (void)hipFree(export_buf);
@@ -209,7 +211,9 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     }
     // two sweeps per pass (K2x2): Laplace control function only (White updates P,Q between sweeps), every owned block >= 5 x 5
     fuse_pairs = opt.inner == TM_INNER_RELAX && !white && !(opt.flags & TM_OPT_SINGLE_SWEEP);
-    for (int64_t b : lp.owned_blocks) fuse_pairs = fuse_pairs && relax2_supported(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
+    // (every block of the mesh, not just the owned ones: the ranks of a job must agree on the schedule -- a pair costs one exchange)
+    for (int64_t b = 0; b < topo.nblocks(); ++b)
+        if (has_hooks || owner[b] == lp.rank) fuse_pairs = fuse_pairs && relax2_supported(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
     if (fuse_pairs) M = vec();
 
     // ---- perimeter rows -> device SoA with rank-local ids
@@ -220,14 +224,14 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         if (!measure && bytes) HIPCHK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
         return d;
     };
-    auto build_table = [&](const std::vector<size_t>& sel, EdgeRowsDev& e, double*& rhs_dev) {
+    auto build_table = [&](const std::vector<const PlanRow*>& sel, EdgeRowsDev& e, double*& rhs_dev) {
         const size_t n = sel.size();
         std::vector<int32_t> h_row(n), h_cols(n * 9, 0), h_metric(n * 4, 0);
         std::vector<int8_t> h_kind(n), h_ncols(n), h_slot(n * 9, 0), h_self(n);
         std::vector<double> h_cx(n * 9, 0.0), h_cy(n * 9, 0.0), h_per(n * 2, 0.0);
         std::vector<uint8_t> h_flags(n);
         for (size_t k = 0; k < n; ++k) {
-            const PlanRow& pr = lp.rows[sel[k]];
+            const PlanRow& pr = *sel[k];
             auto loc = [&](int64_t gid) {
                 const int64_t l = lp.to_local(gid);
                 if (l < 0) throw TmError(TM_E_TOPOLOGY, "internal: column is neither owned nor ghost");
@@ -238,6 +242,8 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
             h_ncols[k] = pr.ncols;
             h_self[k] = pr.self;
             h_flags[k] = pr.flags;
+            // a ghost copy of a row whose rhs is the node's own boundary coordinate takes it from the row's current value
+            if (lp.to_local(pr.gid) >= lp.n_owned) h_flags[k] |= static_cast<uint8_t>((pr.rhs_coord & 3) << 2);
             h_per[2 * k] = pr.per[0];
             h_per[2 * k + 1] = pr.per[1];
             for (int q = 0; q < pr.ncols; ++q) {   // transposed: column q of all rows is contiguous
@@ -264,8 +270,8 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         rhs_dev = arena.alloc_n<double>(n * 2);
         e.rhs = rhs_dev;
     };
-    std::vector<size_t> all(nr);
-    for (size_t k = 0; k < nr; ++k) all[k] = k;
+    std::vector<const PlanRow*> all(nr);
+    for (size_t k = 0; k < nr; ++k) all[k] = &lp.rows[k];
     build_table(all, edge, d_rhs);
     // Relaxation sweeps never have to touch a `fixed` row: it returns its boundary coordinate (smooth.zig:790-795), which the
     // perimeter of every field buffer holds from upload() on.  They run the perimeter-row kernel over the other rows only
@@ -286,7 +292,16 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         if (bj == 0) dyn_mask[kb] |= 4;
         if (bj == topo.nj[b] - 1) dyn_mask[kb] |= 8;
     }
-    if (opt.inner == TM_INNER_RELAX) build_table(nf_rows, edge_nf, d_rhs_nf);
+    if (opt.inner == TM_INNER_RELAX) {
+        std::vector<const PlanRow*> sel;
+        for (size_t k : nf_rows) sel.push_back(&lp.rows[k]);
+        build_table(sel, edge_nf, d_rhs_nf);
+        // multi-rank sweep pairs: the same rows plus the depth-1 ghost rows, evaluated one sweep ahead (LocalPlan::ghost_rows)
+        if (fuse_pairs && has_hooks && !lp.ghost_rows.empty()) {
+            for (const PlanRow& g : lp.ghost_rows) sel.push_back(&g);
+            build_table(sel, edge_nf_g, d_rhs_nf_g);
+        }
+    }
 
     // ---- reductions
     poff.clear();
@@ -370,6 +385,13 @@ void Smoother::upload(const tm_mesh_desc* mesh) {
         }
         HIPCHK(hipMemcpyAsync(d_rhs_nf, h_rhs_nf.data(), sizeof(double) * h_rhs_nf.size(), hipMemcpyHostToDevice, stream));
     }
+    if (d_rhs_nf_g) {   // own rows as above, then the ghost rows' static right-hand sides (coordinate parts come from the row's value)
+        for (const PlanRow& g : lp.ghost_rows) {
+            h_rhs_nf.push_back(g.rhs[0]);
+            h_rhs_nf.push_back(g.rhs[1]);
+        }
+        HIPCHK(hipMemcpyAsync(d_rhs_nf_g, h_rhs_nf.data(), sizeof(double) * h_rhs_nf.size(), hipMemcpyHostToDevice, stream));
+    }
     if (opt.inner == TM_INNER_RELAX) prefill_fixed();
     sync();   // host staging buffers may go away after return
 }
@@ -440,7 +462,8 @@ void Smoother::reduce_update(int nwg, int step, double rtol, double atol) {
 }
 
 // runs `launch`; with profiling on, bracketed by a hipEvent pair on the handle's stream
-void Smoother::profiled(const std::function<void()>& launch, bool counts) {
+void Smoother::profiled(const std::function<void()>& launch, bool counts, hipStream_t on) {
+    if (!on) on = stream;
     if (!profile) {
         launch();
         return;
@@ -460,9 +483,9 @@ void Smoother::profiled(const std::function<void()>& launch, bool counts) {
         ev_start.push_back(e0);
         ev_stop.push_back(e1);
     }
-    HIPCHK(hipEventRecord(ev_start[ev_used], stream));
+    HIPCHK(hipEventRecord(ev_start[ev_used], on));
     launch();
-    HIPCHK(hipEventRecord(ev_stop[ev_used], stream));
+    HIPCHK(hipEventRecord(ev_stop[ev_used], on));
     ev_used += 1;
     if (counts) {
         prof_launches += 1;
@@ -618,7 +641,8 @@ int Smoother::picard_bicgstab(tm_stats& st) {
 //   perimeter rows of X^(k+2)  <- perimeter-row kernel on M (perimeter + ring + exchanged ghost rows are all it reads)
 // With several ranks the K2x2 grid is launched in three parts so that both halo exchanges (of X^k, then of X^(k+1)) travel
 // while workgroups that touch neither perimeter nor ring are running.
-void Smoother::relax2_launch(int subset, bool counts, int dot) {
+void Smoother::relax2_launch(int subset, bool counts, int dot, hipStream_t on) {
+    if (!on) on = stream;
     std::vector<Relax2Block> blocks(lp.owned_blocks.size());
     for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
         const int64_t b = lp.owned_blocks[k];
@@ -635,7 +659,7 @@ void Smoother::relax2_launch(int subset, bool counts, int dot) {
         a.nborder = border_n[k];
         a.partials = partials + static_cast<size_t>(poff2[k]) * MAX_PARTIALS;
     }
-    profiled([&]() { HIPCHK(launch_relax2_blocks(blocks.data(), rows2.data(), static_cast<int>(blocks.size()), dot, subset, stream)); }, counts);
+    profiled([&]() { HIPCHK(launch_relax2_blocks(blocks.data(), rows2.data(), static_cast<int>(blocks.size()), dot, subset, on)); }, counts, on);
 }
 
 // want_partials: only the pass whose displacement norms are read back pays for them (the last one of an iterate() call)
@@ -651,24 +675,32 @@ void Smoother::relax_pair(bool want_partials) {
     std::swap(X, U);
 }
 
-// Sweep pairs of a rank that has neighbours: two streams.  The interior pass of a pair (workgroups that touch neither the
-// perimeter nor the first-interior ring: ~88 % of a 4096^2 block) needs nothing but interior rows of its input, so it starts as
-// soon as the previous pair's border workgroups are done -- while, on the side stream, the previous pair's second exchange
-// (X^(k+1) perimeter + ring), its closing perimeter rows, this pair's first exchange (X^(k+2)) and its opening perimeter rows
-// run one after the other.  Only the border workgroups wait for that chain.
-//     main:  I(0)      B(0) | I(1) ................ B(1) | I(2) ...
-//     side:  x E1(0) /      \ x E2(0) x E1(1) ..... /    \ x E2(1) x E1(2) ...          x = gather + halo exchange
-// Buffers: A = complete input, Bf = output, M = perimeter + ring of the intermediate field; A and Bf swap after every pair.
+// Sweep pairs of a rank that has neighbours.  What bounds a pair is not bandwidth but the chain of DEPENDENT steps through the
+// block's border: border workgroups of pair k -> perimeter rows of X^(k+2) -> halo exchange -> perimeter (+ ghost) rows of
+// X^(k+3) -> border workgroups of pair k+1.  A dependency between two queues costs ~13 us on this part (event record + stream
+// wait, rocprofv3 trace in profiles/), one inside a queue 1-7 us, so the whole chain lives on ONE high-priority stream (`side`)
+// and only the interior pass -- workgroups that touch neither perimeter nor first-interior ring, 88 % of a 4096^2 block, reading
+// nothing but interior rows -- runs on the handle's stream beside it.  The two cross-queue waits per pair (interior pass k+1 after
+// border k, border k+1 after interior pass k) have a whole pass of slack.
+//     side:  x E1g(0) B(0) | E2(0) x E1g(1) ...... B(1) | E2(1) x E1g(2) ...           x = halo exchange (one per pair)
+//     main:  I(0) ........ | I(1) ................      | I(2) ...
+// ONE exchange per pair (depth-2 halo, LocalPlan::ghost_rows): X^k of every remote row my perimeter rows read AND of the rows those
+// read travels; E1g evaluates my perimeter rows and, redundantly, those ghost rows of X^(k+1) (same arithmetic as their owner,
+// bit for bit), so E2 finds its remote operands in M without a second exchange.
+// Buffers: A = complete input, Bf = output, M = perimeter + ring (+ ghost rows) of the intermediate field; A and Bf swap per pair.
 void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
     if (!side) {
-        int least = 0, greatest = 0;   // the side chain is short and latency-critical: let its kernels overtake queued interior workgroups
+        int least = 0, greatest = 0;   // the chain is latency-critical: let its kernels overtake queued interior workgroups
         HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
         HIPCHK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest));
         HIPCHK(hipEventCreateWithFlags(&ev_to_side, hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_to_main, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_inside[0], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_inside[1], hipEventDisableTiming));
     }
-    auto edge_on_side = [&](const double2* in, double2* out, int dot) {
-        HIPCHK(launch_edge_rows(edge_nf, in, in, PQ, nullptr, out, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, side));
+    const EdgeRowsDev& e1 = edge_nf_g.nrows ? edge_nf_g : edge_nf;
+    auto edge_on_side = [&](const EdgeRowsDev& e, const double2* in, double2* out, int dot) {
+        HIPCHK(launch_edge_rows(e, in, in, PQ, nullptr, out, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, side));
     };
     auto exchange_on_side = [&](double2* vec) {
         exchange(vec, side);
@@ -678,27 +710,27 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
     int dot = (npairs == 1 && want_partials_last) ? DOT_DELTA : DOT_NONE;
     fence(stream, side, ev_to_side);   // X is complete on the main stream
     exchange_on_side(X);
-    edge_on_side(X, M, DOT_NONE);      // E1(0): perimeter rows of the intermediate field
+    edge_on_side(e1, X, M, DOT_NONE);    // E1g(0): perimeter rows (own + ghost) of the intermediate field
     relax2_launch(R2_INSIDE, false, dot);
-    fence(side, stream, ev_to_main);
-    relax2_launch(R2_BORDER, true, dot);
+    HIPCHK(hipEventRecord(ev_inside[0], stream));
+    relax2_launch(R2_BORDER, true, dot, side);
     for (uint64_t k = 0; k < npairs; ++k) {
-        fence(stream, side, ev_to_side);   // the border workgroups of pair k have left the ring of the intermediate field in M
-        exchange_on_side(M);
-        edge_on_side(M, U, dot);           // E2(k): perimeter rows of the pair's output
+        HIPCHK(hipEventRecord(ev_to_main, side));   // the border workgroups of pair k are done
+        edge_on_side(edge_nf, M, U, dot);             // E2(k): perimeter rows of the pair's output (ghost operands: M's ghost rows)
+        std::swap(X, U);
         if (k + 1 == npairs) {
-            fence(side, stream, ev_to_main);
-            std::swap(X, U);
+            fence(side, stream, ev_to_main);          // the main stream continues behind the whole chain
             break;
         }
-        // pair k+1: input = this pair's output (interior complete on the main stream, perimeter arriving on the side stream)
-        std::swap(X, U);
+        // pair k+1: input = this pair's output
         dot = (k + 2 == npairs && want_partials_last) ? DOT_DELTA : DOT_NONE;
+        HIPCHK(hipStreamWaitEvent(stream, ev_to_main, 0));   // interior pass k+1 reads rows the border of pair k wrote, and overwrites its input
         relax2_launch(R2_INSIDE, false, dot);
+        HIPCHK(hipEventRecord(ev_inside[(k + 1) & 1], stream));
         exchange_on_side(X);
-        edge_on_side(X, M, DOT_NONE);      // E1(k+1)
-        fence(side, stream, ev_to_main);
-        relax2_launch(R2_BORDER, true, dot);
+        edge_on_side(e1, X, M, DOT_NONE);             // E1g(k+1)
+        HIPCHK(hipStreamWaitEvent(side, ev_inside[k & 1], 0));   // border k+1 reads rows interior pass k wrote, and overwrites ITS input
+        relax2_launch(R2_BORDER, true, dot, side);
     }
 }
 

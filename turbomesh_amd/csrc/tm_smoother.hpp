@@ -72,6 +72,8 @@ struct Smoother {
     // sides carry such rows
     EdgeRowsDev edge_nf;
     double* d_rhs_nf = nullptr;
+    EdgeRowsDev edge_nf_g;          // the same + the depth-1 ghost rows (multi-rank sweep pairs; empty otherwise)
+    double* d_rhs_nf_g = nullptr;
     std::vector<size_t> nf_rows;
     std::vector<int> dyn_mask;
     std::vector<const int32_t*> border_ids;   // per owned block: device list of the K2x2 border tiles
@@ -122,7 +124,7 @@ struct Smoother {
     void exchange_finish(hipStream_t on = nullptr);          // split hooks: make the stream wait for the transfer started by exchange()
     // second stream of a multi-rank relax handle: halo exchanges and perimeter rows of a sweep pair run here, beside the interior pass
     hipStream_t side = nullptr;
-    hipEvent_t ev_to_side = nullptr, ev_to_main = nullptr;
+    hipEvent_t ev_to_side = nullptr, ev_to_main = nullptr, ev_inside[2] = {nullptr, nullptr};
     void fence(hipStream_t from, hipStream_t to, hipEvent_t ev);
     void relax_pairs_pipelined(uint64_t npairs, bool want_partials_last);
     bool exchange_pending = false;
@@ -138,8 +140,8 @@ struct Smoother {
     int picard_bicgstab(tm_stats& st);
     void relax_sweeps(uint64_t n, tm_stats& st);
     void relax_pair(bool want_partials);
-    void profiled(const std::function<void()>& launch, bool counts = true);
-    void relax2_launch(int subset, bool counts, int dot);
+    void profiled(const std::function<void()>& launch, bool counts = true, hipStream_t on = nullptr);
+    void relax2_launch(int subset, bool counts, int dot, hipStream_t on = nullptr);
 };
 
 }  // namespace tmh

@@ -46,6 +46,10 @@ def local_plan(mesh, owner, rank, world):
             "send_count": arr(info.send_count, info.npeers), "recv_offset": arr(info.recv_offset, info.npeers),
             "recv_count": arr(info.recv_count, info.npeers), "send_first": arr(info.send_first, info.npeers),
             "direct_send": bool(info.direct_send),
+            "ghost_row_gid": arr(info.ghost_row_gid, info.n_ghost_rows),
+            "ghost_row_kind": np.ctypeslib.as_array(info.ghost_row_kind, (info.n_ghost_rows,)).copy() if info.n_ghost_rows else np.zeros(0, dtype=np.int32),
+            "ghost_row_cols": (np.ctypeslib.as_array(info.ghost_row_cols, (info.n_ghost_rows * 9,)).reshape(-1, 9).copy() if info.n_ghost_rows
+                               else np.zeros((0, 9), dtype=np.int64)),
         }
     finally:
         _capi.lib().tm_plan_local_free(C.byref(info))
