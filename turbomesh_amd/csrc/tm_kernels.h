@@ -94,25 +94,34 @@ struct Relax2Batch {
 hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, int subset, hipStream_t stream);
 void tune_fuse_rows(int rows);
 
-// ---- K4/K5 perimeter rows (device SoA, built on the host by tm_plan)
+// ---- K4/K5 perimeter rows.  The rows of an interface are REGULAR: along a connection the row id, every column id and the
+// four metric neighbours advance by constant strides while kind, column count, stencil slots and static coefficients stay
+// the same (smooth.zig:518-616 fixes the column order per connection, not per point).  The host therefore compresses the
+// per-row table of tm_plan into RUNS; a workgroup serves one stretch of one run, reads the run's descriptor through the
+// scalar cache and computes its indices arithmetically, so the only vector loads of a row are the VALUES it gathers --
+// one level of memory latency instead of two (index tables -> values), which is what a perimeter-row pass costs when it
+// runs beside a bandwidth-saturating interior pass.  Irregular rows (connection end points, junctions) are runs of one.
+struct EdgeRun {
+    int32_t first, count;            // positions [first, first + count) of the run's rows in `rhs` (run order)
+    int32_t row0, row_stride;        // local vector index of row k: row0 + k * row_stride
+    int32_t col0[9], col_stride[9];  // its columns, ascending GLOBAL id order (the reference's CSR order)
+    int32_t met0[4], met_stride[4];  // smoothed rows: im1_j, ip1_j, i_jm1, i_jp1
+    int8_t kind, ncols, self;        // BlockBoundaryPointKind (5 = interior node of a remote block), #columns, diagonal position
+    uint8_t flags;                   // bit0 periodic, bit1 swap (Q,P), bit2 / bit3: rhs_x / rhs_y = the row's current value (ghost copies)
+    int8_t slot[9];                  // smoothed rows: stencil slot per column
+    int8_t _pad[3];
+    double cx[9], cy[9];             // static x / y system coefficients
+    double per[2];                   // periodicity of the row's connection
+};
 struct EdgeRowsDev {
-    int nrows = 0;
-    const int32_t* row = nullptr;       // [nrows] local vector index of the row
-    const int8_t* kind = nullptr;       // [nrows] BlockBoundaryPointKind
-    const int8_t* ncols = nullptr;      // [nrows]
-    // per-column arrays are stored TRANSPOSED ([9][nrows], [4][nrows]) so that a wave reads them coalesced
-    const int32_t* cols = nullptr;      // [9*nrows] local vector indices, ascending GLOBAL id order
-    const double* cx = nullptr;         // [nrows*9] static x-system coefficients
-    const double* cy = nullptr;         // [nrows*9] static y-system coefficients
-    const int8_t* slot = nullptr;       // [nrows*9] smoothed rows: stencil slot per column
-    const int32_t* metric = nullptr;    // [nrows*4] smoothed rows: local ids of im1_j, ip1_j, i_jm1, i_jp1
-    const double* per = nullptr;        // [nrows*2] periodicity of the row's connection
-    const uint8_t* flags = nullptr;     // [nrows] bit0 periodic, bit1 swap (Q,P)
-    const double* rhs = nullptr;        // [nrows*2] static right-hand side
-    const int8_t* self = nullptr;       // [nrows] position of the diagonal entry within cols
+    int nrows = 0;                      // rows in all runs
+    int nwg = 0;                        // workgroups of a launch (= partial-sum rows it writes)
+    const EdgeRun* runs = nullptr;
+    const int32_t* wg_run = nullptr;    // [nwg] run served by workgroup w
+    const int32_t* wg_k0 = nullptr;     // [nwg] first point of the run it serves
+    const double* rhs = nullptr;        // [nrows*2] static right-hand side, run order
 };
 constexpr int EDGE_BLOCK = 128;
-inline int edge_rows_nwg(int nrows) { return (nrows + EDGE_BLOCK - 1) / EDGE_BLOCK; }
 // out/in/xk/pq/aux are the rank-local vectors (owned rows then ghost rows)
 hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const double2* xk, const double2* pq, const double2* aux,
                             double2* out, double omega, int mode, int dot, double* partials, hipStream_t stream);

@@ -928,87 +928,89 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const d
                                                           const double2* __restrict__ xk, const double2* __restrict__ pq,
                                                           const double2* __restrict__ aux, double2* __restrict__ out, double omega,
                                                           double* partials) {
-    const int r = blockIdx.x * EDGE_BLOCK + threadIdx.x;
+    // one workgroup = one stretch of one run: everything read through R is workgroup-uniform (scalar loads)
+    const EdgeRun& R = e.runs[__builtin_amdgcn_readfirstlane(e.wg_run[blockIdx.x])];
+    const int k = __builtin_amdgcn_readfirstlane(e.wg_k0[blockIdx.x]) + static_cast<int>(threadIdx.x);
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
-    if (r < e.nrows) {
-        const int row = e.row[r];
-        const int kind = e.kind[r];
-        const int nc = e.ncols[r];
-        const int self = e.self[r];
+    if (k < R.count) {
+        const int row = R.row0 + k * R.row_stride;
+        const int kind = R.kind;
+        const int nc = R.ncols;
+        const int self = R.self;
+        auto col = [&](int q) { return R.col0[q] + k * R.col_stride[q]; };
         double sx = 0.0, sy = 0.0, rhs_x, rhs_y, diag_x, diag_y;
         if (MODE == MODE_RELAX && kind == 5) {
             // interior node of a REMOTE block, evaluated here as a ghost row (depth-2 halo): K2's own arithmetic on the gathered
             // 3 x 3 neighbourhood (columns in (i-1,j-1) ... (i+1,j+1) order), bit-identical to what the owner's K2 / K2x2 stores
-            const size_t n = e.nrows;
-            const double2 ml = in[e.cols[r]], mc = in[e.cols[n + r]], mr = in[e.cols[2 * n + r]];
-            const double2 cl = in[e.cols[3 * n + r]], cc = in[e.cols[4 * n + r]], cr = in[e.cols[5 * n + r]];
-            const double2 pl = in[e.cols[6 * n + r]], pc = in[e.cols[7 * n + r]], pr = in[e.cols[8 * n + r]];
+            const double2 ml = in[col(0)], mc = in[col(1)], mr = in[col(2)];
+            const double2 cl = in[col(3)], cc = in[col(4)], cr = in[col(5)];
+            const double2 pl = in[col(6)], pc = in[col(7)], pr = in[col(8)];
             const double2 c_e = sub2(cr, cl);
             double2 delta;
             out[row] = winslow_row<MODE_RELAX, false>(mc, sub2(mr, ml), cc, c_e, add2(cr, cl), pc, sub2(pr, pl), sub2(pc, mc), c_e, 0.0, 0.0, omega, delta);
         } else {
-        if (kind == 1 /* smoothed */) {
-            const double2 im1_j = xk[e.metric[r]], ip1_j = xk[e.metric[e.nrows + r]], i_jm1 = xk[e.metric[2 * static_cast<size_t>(e.nrows) + r]];
-            double2 i_jp1 = xk[e.metric[3 * static_cast<size_t>(e.nrows) + r]];
-            const bool periodic = e.flags[r] & 1;
-            const double per_x = e.per[2 * r], per_y = e.per[2 * r + 1];
-            if (periodic) {   // types.add(p, types.neg(periodicity)), smooth.zig:1032
-                i_jp1.x = i_jp1.x + (-per_x);
-                i_jp1.y = i_jp1.y + (-per_y);
-            }
-            const double2 cf = pq ? pq[row] : make_double2(0.0, 0.0);
-            // periodic rows pass (P,Q), non-periodic rows pass (Q,P): smooth.zig:1040-1041 vs 1082-1083
-            const double P = periodic ? cf.x : cf.y, Q = periodic ? cf.y : cf.x;
-            double c[9];
-            stencil_coefs<true>(im1_j, ip1_j, i_jm1, i_jp1, P, Q, c);
+            if (kind == 1 /* smoothed */) {
+                const double2 im1_j = xk[R.met0[0] + k * R.met_stride[0]], ip1_j = xk[R.met0[1] + k * R.met_stride[1]];
+                const double2 i_jm1 = xk[R.met0[2] + k * R.met_stride[2]];
+                double2 i_jp1 = xk[R.met0[3] + k * R.met_stride[3]];
+                const bool periodic = R.flags & 1;
+                const double per_x = R.per[0], per_y = R.per[1];
+                if (periodic) {   // types.add(p, types.neg(periodicity)), smooth.zig:1032
+                    i_jp1.x = i_jp1.x + (-per_x);
+                    i_jp1.y = i_jp1.y + (-per_y);
+                }
+                const double2 cf = pq ? pq[row] : make_double2(0.0, 0.0);
+                // periodic rows pass (P,Q), non-periodic rows pass (Q,P): smooth.zig:1040-1041 vs 1082-1083
+                const double P = periodic ? cf.x : cf.y, Q = periodic ? cf.y : cf.x;
+                double c[9];
+                stencil_coefs<true>(im1_j, ip1_j, i_jm1, i_jp1, P, Q, c);
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                const double ck = pick9(c, e.slot[static_cast<size_t>(k) * e.nrows + r]);
-                const double2 w = in[e.cols[static_cast<size_t>(k) * e.nrows + r]];
-                sx += ck * w.x;
-                sy += ck * w.y;
-            }
-            diag_x = diag_y = c[S_I_J];
-            if (periodic) {   // smooth.zig:1060-1061
-                const double cs = c[S_IM1_JP1] + c[S_I_JP1] + c[S_IP1_JP1];
-                rhs_x = per_x * cs;
-                rhs_y = per_y * cs;
+                for (int q = 0; q < 9; ++q) {
+                    const double ck = pick9(c, R.slot[q]);
+                    const double2 w = in[col(q)];
+                    sx += ck * w.x;
+                    sy += ck * w.y;
+                }
+                diag_x = diag_y = c[S_I_J];
+                if (periodic) {   // smooth.zig:1060-1061
+                    const double cs = c[S_IM1_JP1] + c[S_I_JP1] + c[S_IP1_JP1];
+                    rhs_x = per_x * cs;
+                    rhs_y = per_y * cs;
+                } else {
+                    rhs_x = 0.0;
+                    rhs_y = 0.0;
+                }
             } else {
-                rhs_x = 0.0;
-                rhs_y = 0.0;
-            }
-        } else {
-            diag_x = 0.0;
-            diag_y = 0.0;
+                diag_x = 0.0;
+                diag_y = 0.0;
 #pragma unroll
-            for (int k = 0; k < 9; ++k) {
-                if (k < nc) {
-                    const double ax = e.cx[static_cast<size_t>(k) * e.nrows + r], ay = e.cy[static_cast<size_t>(k) * e.nrows + r];
-                    const double2 w = in[e.cols[static_cast<size_t>(k) * e.nrows + r]];
-                    sx += ax * w.x;
-                    sy += ay * w.y;
-                    if (k == self) {
-                        diag_x = ax;
-                        diag_y = ay;
+                for (int q = 0; q < 9; ++q) {
+                    if (q < nc) {
+                        const double ax = R.cx[q], ay = R.cy[q];
+                        const double2 w = in[col(q)];
+                        sx += ax * w.x;
+                        sy += ay * w.y;
+                        if (q == self) {
+                            diag_x = ax;
+                            diag_y = ay;
+                        }
                     }
                 }
+                rhs_x = e.rhs[2 * (R.first + k)];
+                rhs_y = e.rhs[2 * (R.first + k) + 1];
             }
-            rhs_x = e.rhs[2 * r];
-            rhs_y = e.rhs[2 * r + 1];
-        }
-        const double2 w_self = in[row];
-        // ghost copies of rows whose right-hand side is the node's own boundary coordinate (fixed rows, the x-system of sliding
-        // rows): that coordinate IS the row's current value -- such a row reproduces it in every sweep
-        const int fl = e.flags[r];
-        if (fl & 4) rhs_x = w_self.x;
-        if (fl & 8) rhs_y = w_self.y;
-        // constraint rows are enforced exactly in a relaxation sweep (omega = 1); smoothed rows relax like interior rows
-        const double om = (kind == 1) ? omega : 1.0;
-        double2 o;
-        o.x = row_out<MODE>(sx, rhs_x, diag_x, w_self.x, om);
-        o.y = row_out<MODE>(sy, rhs_y, diag_y, w_self.y, om);
-        out[row] = o;
-        accumulate<DOT>(acc, w_self, o, (DOT == DOT_AUX || DOT == DOT_AUX2) ? aux[row] : ((DOT == DOT_DELTA) ? make_double2(o.x - w_self.x, o.y - w_self.y) : o));
+            const double2 w_self = in[row];
+            // ghost copies of rows whose right-hand side is the node's own boundary coordinate (fixed rows, the x-system of sliding
+            // rows): that coordinate IS the row's current value -- such a row reproduces it in every sweep
+            if (R.flags & 4) rhs_x = w_self.x;
+            if (R.flags & 8) rhs_y = w_self.y;
+            // constraint rows are enforced exactly in a relaxation sweep (omega = 1); smoothed rows relax like interior rows
+            const double om = (kind == 1) ? omega : 1.0;
+            double2 o;
+            o.x = row_out<MODE>(sx, rhs_x, diag_x, w_self.x, om);
+            o.y = row_out<MODE>(sy, rhs_y, diag_y, w_self.y, om);
+            out[row] = o;
+            accumulate<DOT>(acc, w_self, o, (DOT == DOT_AUX || DOT == DOT_AUX2) ? aux[row] : ((DOT == DOT_DELTA) ? make_double2(o.x - w_self.x, o.y - w_self.y) : o));
         }
     }
     if (DOT != DOT_NONE) block_partials<EDGE_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
@@ -1017,7 +1019,7 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const d
 hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const double2* xk, const double2* pq, const double2* aux,
                             double2* out, double omega, int mode, int dot, double* partials, hipStream_t st) {
     if (e.nrows == 0) return hipSuccess;
-    const dim3 grid(edge_rows_nwg(e.nrows)), block(EDGE_BLOCK);
+    const dim3 grid(e.nwg), block(EDGE_BLOCK);
 #define TM_EDGE(M, D)                                                                                                  \
     if (mode == M && dot == D) {                                                                                       \
         hipLaunchKernelGGL((k_edge_rows<M, D>), grid, block, 0, st, e, in, xk, pq, aux, out, omega, partials);         \
@@ -1171,17 +1173,18 @@ hipError_t launch_soa_planes(const double2* in, double* plane0, double* plane1, 
 // right-hand side of the perimeter rows (interior rows have b = 0)
 __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rhs(EdgeRowsDev e, const double2* __restrict__ xk, const double2* __restrict__ pq,
                                                          double2* __restrict__ rhs_out, int scaled, double* partials) {
-    const int r = blockIdx.x * EDGE_BLOCK + threadIdx.x;
+    const EdgeRun& R = e.runs[__builtin_amdgcn_readfirstlane(e.wg_run[blockIdx.x])];
+    const int k = __builtin_amdgcn_readfirstlane(e.wg_k0[blockIdx.x]) + static_cast<int>(threadIdx.x);
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
-    if (r < e.nrows) {
-        const int row = e.row[r];
-        const int kind = e.kind[r];
+    if (k < R.count) {
+        const int row = R.row0 + k * R.row_stride;
         double rhs_x, rhs_y, diag_x, diag_y;
-        if (kind == 1) {
-            const double2 im1_j = xk[e.metric[r]], ip1_j = xk[e.metric[e.nrows + r]], i_jm1 = xk[e.metric[2 * static_cast<size_t>(e.nrows) + r]];
-            double2 i_jp1 = xk[e.metric[3 * static_cast<size_t>(e.nrows) + r]];
-            const bool periodic = e.flags[r] & 1;
-            const double per_x = e.per[2 * r], per_y = e.per[2 * r + 1];
+        if (R.kind == 1) {
+            const double2 im1_j = xk[R.met0[0] + k * R.met_stride[0]], ip1_j = xk[R.met0[1] + k * R.met_stride[1]];
+            const double2 i_jm1 = xk[R.met0[2] + k * R.met_stride[2]];
+            double2 i_jp1 = xk[R.met0[3] + k * R.met_stride[3]];
+            const bool periodic = R.flags & 1;
+            const double per_x = R.per[0], per_y = R.per[1];
             if (periodic) {
                 i_jp1.x = i_jp1.x + (-per_x);
                 i_jp1.y = i_jp1.y + (-per_y);
@@ -1195,11 +1198,17 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rhs(EdgeRowsDev e, const do
             rhs_x = periodic ? per_x * cs : 0.0;
             rhs_y = periodic ? per_y * cs : 0.0;
         } else {
-            const int self = e.self[r];
-            diag_x = e.cx[static_cast<size_t>(self) * e.nrows + r];
-            diag_y = e.cy[static_cast<size_t>(self) * e.nrows + r];
-            rhs_x = e.rhs[2 * r];
-            rhs_y = e.rhs[2 * r + 1];
+            const int self = R.self;
+            diag_x = 0.0;
+            diag_y = 0.0;
+#pragma unroll
+            for (int q = 0; q < 9; ++q)
+                if (q == self) {
+                    diag_x = R.cx[q];
+                    diag_y = R.cy[q];
+                }
+            rhs_x = e.rhs[2 * (R.first + k)];
+            rhs_y = e.rhs[2 * (R.first + k) + 1];
         }
         const double bx = rhs_x * ((diag_x == 0.0) ? 1.0 : 1.0 / diag_x);
         const double by = rhs_y * ((diag_y == 0.0) ? 1.0 : 1.0 / diag_y);
@@ -1212,7 +1221,7 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rhs(EdgeRowsDev e, const do
 hipError_t launch_edge_rhs(const EdgeRowsDev& e, const double2* xk, const double2* pq, double2* rhs_out, int scaled, double* partials,
                            hipStream_t st) {
     if (e.nrows == 0) return hipSuccess;
-    hipLaunchKernelGGL(k_edge_rhs, dim3(edge_rows_nwg(e.nrows)), dim3(EDGE_BLOCK), 0, st, e, xk, pq, rhs_out, scaled, partials);
+    hipLaunchKernelGGL(k_edge_rhs, dim3(e.nwg), dim3(EDGE_BLOCK), 0, st, e, xk, pq, rhs_out, scaled, partials);
     return hipGetLastError();
 }
 

@@ -224,55 +224,126 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         if (!measure && bytes) HIPCHK(hipMemcpy(d, src, bytes, hipMemcpyHostToDevice));
         return d;
     };
-    auto build_table = [&](const std::vector<const PlanRow*>& sel, EdgeRowsDev& e, double*& rhs_dev) {
+    // Per-row table -> runs (tm_kernels.h EdgeRun).  Rows are grouped by everything that must be equal along a run (static fields
+    // and the grid line of their block they lie on), sorted by row id within a group and cut wherever an index stops advancing by
+    // the stride of the stretch.  order[p] = position in `sel` of the row whose right-hand side sits at position p of e.rhs.
+    auto build_table = [&](const std::vector<const PlanRow*>& sel, EdgeRowsDev& e, double*& rhs_dev, std::vector<int32_t>& order) {
         const size_t n = sel.size();
-        std::vector<int32_t> h_row(n), h_cols(n * 9, 0), h_metric(n * 4, 0);
-        std::vector<int8_t> h_kind(n), h_ncols(n), h_slot(n * 9, 0), h_self(n);
-        std::vector<double> h_cx(n * 9, 0.0), h_cy(n * 9, 0.0), h_per(n * 2, 0.0);
-        std::vector<uint8_t> h_flags(n);
+        struct HostRow {
+            int32_t row, col[9], met[4];
+            uint8_t flags;
+            int64_t line;   // (block, grid line) the node lies on: rows of different lines never share a run
+        };
+        std::vector<HostRow> hr(n);
+        auto loc = [&](int64_t gid) {
+            const int64_t l = lp.to_local(gid);
+            if (l < 0) throw TmError(TM_E_TOPOLOGY, "internal: column is neither owned nor ghost");
+            return static_cast<int32_t>(l);
+        };
         for (size_t k = 0; k < n; ++k) {
             const PlanRow& pr = *sel[k];
-            auto loc = [&](int64_t gid) {
-                const int64_t l = lp.to_local(gid);
-                if (l < 0) throw TmError(TM_E_TOPOLOGY, "internal: column is neither owned nor ghost");
-                return static_cast<int32_t>(l);
-            };
-            h_row[k] = loc(pr.gid);
-            h_kind[k] = pr.kind;
-            h_ncols[k] = pr.ncols;
-            h_self[k] = pr.self;
-            h_flags[k] = pr.flags;
+            HostRow& h = hr[k];
+            std::memset(&h, 0, sizeof(h));
+            h.row = loc(pr.gid);
+            h.flags = pr.flags;
             // a ghost copy of a row whose rhs is the node's own boundary coordinate takes it from the row's current value
-            if (lp.to_local(pr.gid) >= lp.n_owned) h_flags[k] |= static_cast<uint8_t>((pr.rhs_coord & 3) << 2);
-            h_per[2 * k] = pr.per[0];
-            h_per[2 * k + 1] = pr.per[1];
-            for (int q = 0; q < pr.ncols; ++q) {   // transposed: column q of all rows is contiguous
-                h_cols[q * n + k] = loc(pr.col[q]);
-                h_cx[q * n + k] = pr.cx[q];
-                h_cy[q * n + k] = pr.cy[q];
-                h_slot[q * n + k] = pr.slot[q];
-            }
+            if (h.row >= lp.n_owned) h.flags |= static_cast<uint8_t>((pr.rhs_coord & 3) << 2);
+            for (int q = 0; q < pr.ncols; ++q) h.col[q] = loc(pr.col[q]);
             if (pr.kind == KIND_SMOOTHED)
-                for (int q = 0; q < 4; ++q) h_metric[q * n + k] = loc(pr.metric[q]);
+                for (int q = 0; q < 4; ++q) h.met[q] = loc(pr.metric[q]);
+            int64_t b = topo.nblocks() - 1;
+            while (pr.gid < topo.start[b]) --b;
+            const int64_t flat = pr.gid - topo.start[b], bi = flat / topo.nj[b], bj = flat % topo.nj[b];
+            const bool on_row = bi <= 1 || bi >= topo.ni[b] - 2;
+            h.line = (b << 34) | (static_cast<int64_t>(on_row ? 0 : 1) << 33) | (on_row ? bi : bj);
         }
+        auto same_static = [&](size_t x, size_t y) {
+            const PlanRow &p = *sel[x], &q = *sel[y];
+            return p.kind == q.kind && p.ncols == q.ncols && p.self == q.self && hr[x].flags == hr[y].flags && hr[x].line == hr[y].line &&
+                   std::memcmp(p.slot, q.slot, sizeof(p.slot)) == 0 && std::memcmp(p.cx, q.cx, sizeof(p.cx)) == 0 &&
+                   std::memcmp(p.cy, q.cy, sizeof(p.cy)) == 0 && std::memcmp(p.per, q.per, sizeof(p.per)) == 0;
+        };
+        auto static_less = [&](size_t x, size_t y) {   // any strict weak order that is consistent with same_static
+            const PlanRow &p = *sel[x], &q = *sel[y];
+            if (hr[x].line != hr[y].line) return hr[x].line < hr[y].line;
+            if (p.kind != q.kind) return p.kind < q.kind;
+            if (p.ncols != q.ncols) return p.ncols < q.ncols;
+            if (p.self != q.self) return p.self < q.self;
+            if (hr[x].flags != hr[y].flags) return hr[x].flags < hr[y].flags;
+            int c = std::memcmp(p.slot, q.slot, sizeof(p.slot));
+            if (c) return c < 0;
+            c = std::memcmp(p.cx, q.cx, sizeof(p.cx));
+            if (c) return c < 0;
+            c = std::memcmp(p.cy, q.cy, sizeof(p.cy));
+            if (c) return c < 0;
+            c = std::memcmp(p.per, q.per, sizeof(p.per));
+            if (c) return c < 0;
+            return hr[x].row < hr[y].row;
+        };
+        std::vector<size_t> idx(n);
+        for (size_t k = 0; k < n; ++k) idx[k] = k;
+        std::sort(idx.begin(), idx.end(), static_less);
+        std::vector<EdgeRun> runs;
+        order.clear();
+        for (size_t p = 0; p < n;) {
+            const size_t k0 = idx[p];
+            const PlanRow& pr = *sel[k0];
+            EdgeRun R;
+            std::memset(&R, 0, sizeof(R));
+            R.first = static_cast<int32_t>(p);
+            R.count = 1;
+            R.row0 = hr[k0].row;
+            R.kind = pr.kind;
+            R.ncols = pr.ncols;
+            R.self = pr.self;
+            R.flags = hr[k0].flags;
+            std::memcpy(R.slot, pr.slot, sizeof(R.slot));
+            std::memcpy(R.cx, pr.cx, sizeof(R.cx));
+            std::memcpy(R.cy, pr.cy, sizeof(R.cy));
+            std::memcpy(R.per, pr.per, sizeof(R.per));
+            for (int q = 0; q < 9; ++q) R.col0[q] = hr[k0].col[q];
+            for (int q = 0; q < 4; ++q) R.met0[q] = hr[k0].met[q];
+            size_t e_ = p + 1;
+            if (e_ < n && same_static(k0, idx[e_])) {   // strides from the second row, then as far as they hold
+                const HostRow& h1 = hr[idx[e_]];
+                R.row_stride = h1.row - R.row0;
+                for (int q = 0; q < 9; ++q) R.col_stride[q] = h1.col[q] - R.col0[q];
+                for (int q = 0; q < 4; ++q) R.met_stride[q] = h1.met[q] - R.met0[q];
+                auto fits = [&](size_t j) {
+                    if (!same_static(k0, idx[j])) return false;
+                    const HostRow& h = hr[idx[j]];
+                    const int32_t kk = static_cast<int32_t>(j - p);
+                    if (h.row != R.row0 + kk * R.row_stride) return false;
+                    for (int q = 0; q < 9; ++q)
+                        if (h.col[q] != R.col0[q] + kk * R.col_stride[q]) return false;
+                    for (int q = 0; q < 4; ++q)
+                        if (h.met[q] != R.met0[q] + kk * R.met_stride[q]) return false;
+                    return true;
+                };
+                while (e_ < n && fits(e_)) ++e_;
+                R.count = static_cast<int32_t>(e_ - p);
+            }
+            for (size_t j = p; j < e_; ++j) order.push_back(static_cast<int32_t>(idx[j]));
+            runs.push_back(R);
+            p = e_;
+        }
+        std::vector<int32_t> wg_run, wg_k0;
+        for (size_t r = 0; r < runs.size(); ++r)
+            for (int32_t k0 = 0; k0 < runs[r].count; k0 += EDGE_BLOCK) {
+                wg_run.push_back(static_cast<int32_t>(r));
+                wg_k0.push_back(k0);
+            }
         e.nrows = static_cast<int>(n);
-        e.row = static_cast<int32_t*>(up(h_row.data(), n * 4));
-        e.kind = static_cast<int8_t*>(up(h_kind.data(), n));
-        e.ncols = static_cast<int8_t*>(up(h_ncols.data(), n));
-        e.cols = static_cast<int32_t*>(up(h_cols.data(), n * 9 * 4));
-        e.cx = static_cast<double*>(up(h_cx.data(), n * 9 * 8));
-        e.cy = static_cast<double*>(up(h_cy.data(), n * 9 * 8));
-        e.slot = static_cast<int8_t*>(up(h_slot.data(), n * 9));
-        e.metric = static_cast<int32_t*>(up(h_metric.data(), n * 4 * 4));
-        e.per = static_cast<double*>(up(h_per.data(), n * 2 * 8));
-        e.flags = static_cast<uint8_t*>(up(h_flags.data(), n));
-        e.self = static_cast<int8_t*>(up(h_self.data(), n));
+        e.nwg = static_cast<int>(wg_run.size());
+        e.runs = static_cast<const EdgeRun*>(up(runs.data(), runs.size() * sizeof(EdgeRun)));
+        e.wg_run = static_cast<const int32_t*>(up(wg_run.data(), wg_run.size() * 4));
+        e.wg_k0 = static_cast<const int32_t*>(up(wg_k0.data(), wg_k0.size() * 4));
         rhs_dev = arena.alloc_n<double>(n * 2);
         e.rhs = rhs_dev;
     };
     std::vector<const PlanRow*> all(nr);
     for (size_t k = 0; k < nr; ++k) all[k] = &lp.rows[k];
-    build_table(all, edge, d_rhs);
+    build_table(all, edge, d_rhs, order_all);
     // Relaxation sweeps never have to touch a `fixed` row: it returns its boundary coordinate (smooth.zig:790-795), which the
     // perimeter of every field buffer holds from upload() on.  They run the perimeter-row kernel over the other rows only
     // (none at all for a block with fixed walls), and the K2x2 workgroups along sides without such rows do not have to wait
@@ -295,11 +366,11 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     if (opt.inner == TM_INNER_RELAX) {
         std::vector<const PlanRow*> sel;
         for (size_t k : nf_rows) sel.push_back(&lp.rows[k]);
-        build_table(sel, edge_nf, d_rhs_nf);
+        build_table(sel, edge_nf, d_rhs_nf, order_nf);
         // multi-rank sweep pairs: the same rows plus the depth-1 ghost rows, evaluated one sweep ahead (LocalPlan::ghost_rows)
         if (fuse_pairs && has_hooks && !lp.ghost_rows.empty()) {
             for (const PlanRow& g : lp.ghost_rows) sel.push_back(&g);
-            build_table(sel, edge_nf_g, d_rhs_nf_g);
+            build_table(sel, edge_nf_g, d_rhs_nf_g, order_nf_g);
         }
     }
 
@@ -311,7 +382,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         off += apply_block_nwg(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
     }
     poff_edge = off;
-    off += edge_rows_nwg(opt.inner == TM_INNER_RELAX ? edge_nf.nrows : edge.nrows);   // a relax handle only ever launches the non-fixed rows
+    off += (opt.inner == TM_INNER_RELAX ? edge_nf.nwg : edge.nwg);   // a relax handle only ever launches the non-fixed rows
     nwg_apply = off;
     if (fuse_pairs) {
         poff2.clear();
@@ -327,7 +398,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
             border_ids.push_back(static_cast<const int32_t*>(up(ids.data(), ids.size() * 4)));
         }
         poff2_edge = off2;
-        nwg_apply2 = off2 + edge_rows_nwg(edge_nf.nrows);
+        nwg_apply2 = off2 + edge_nf.nwg;
     }
     nwg_vec = vec_nwg(n_owned);
     partials = arena.alloc_n<double>(static_cast<uint64_t>(std::max(std::max(nwg_apply, nwg_apply2), nwg_vec)) * MAX_PARTIALS);
@@ -376,22 +447,26 @@ void Smoother::upload(const tm_mesh_desc* mesh) {
             if (pr.rhs_coord & 2) h_rhs[2 * k + 1] = xy[1];
         }
     }
-    if (!h_rhs.empty()) HIPCHK(hipMemcpyAsync(d_rhs, h_rhs.data(), sizeof(double) * h_rhs.size(), hipMemcpyHostToDevice, stream));
-    std::vector<double> h_rhs_nf(nf_rows.size() * 2);
-    if (d_rhs_nf && !nf_rows.empty()) {
-        for (size_t k = 0; k < nf_rows.size(); ++k) {
-            h_rhs_nf[2 * k] = h_rhs[2 * nf_rows[k]];
-            h_rhs_nf[2 * k + 1] = h_rhs[2 * nf_rows[k] + 1];
+    // device right-hand sides are stored in run order (build_table: order[p] = row of the selection at position p)
+    std::vector<double> staged;
+    auto put = [&](double* dev, const std::vector<int32_t>& order, const std::function<const double*(int32_t)>& rhs_of) {
+        if (!dev || order.empty()) return;
+        const size_t base = staged.size();
+        staged.resize(base + 2 * order.size());
+        for (size_t p = 0; p < order.size(); ++p) {
+            const double* v = rhs_of(order[p]);
+            staged[base + 2 * p] = v[0];
+            staged[base + 2 * p + 1] = v[1];
         }
-        HIPCHK(hipMemcpyAsync(d_rhs_nf, h_rhs_nf.data(), sizeof(double) * h_rhs_nf.size(), hipMemcpyHostToDevice, stream));
-    }
-    if (d_rhs_nf_g) {   // own rows as above, then the ghost rows' static right-hand sides (coordinate parts come from the row's value)
-        for (const PlanRow& g : lp.ghost_rows) {
-            h_rhs_nf.push_back(g.rhs[0]);
-            h_rhs_nf.push_back(g.rhs[1]);
-        }
-        HIPCHK(hipMemcpyAsync(d_rhs_nf_g, h_rhs_nf.data(), sizeof(double) * h_rhs_nf.size(), hipMemcpyHostToDevice, stream));
-    }
+        HIPCHK(hipMemcpyAsync(dev, staged.data() + base, sizeof(double) * 2 * order.size(), hipMemcpyHostToDevice, stream));
+    };
+    staged.reserve(2 * (order_all.size() + order_nf.size() + order_nf_g.size()));   // no reallocation while copies are in flight
+    put(d_rhs, order_all, [&](int32_t k) { return &h_rhs[2 * static_cast<size_t>(k)]; });
+    put(d_rhs_nf, order_nf, [&](int32_t k) { return &h_rhs[2 * nf_rows[k]]; });
+    // own rows as above, then the ghost rows' static right-hand sides (coordinate parts come from the row's value)
+    put(d_rhs_nf_g, order_nf_g, [&](int32_t k) {
+        return static_cast<size_t>(k) < nf_rows.size() ? &h_rhs[2 * nf_rows[k]] : lp.ghost_rows[static_cast<size_t>(k) - nf_rows.size()].rhs;
+    });
     if (opt.inner == TM_INNER_RELAX) prefill_fixed();
     sync();   // host staging buffers may go away after return
 }
@@ -565,7 +640,7 @@ int Smoother::picard_bicgstab(tm_stats& st) {
     HIPCHK(hipMemcpyAsync(U, X, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));
     // tolerance from ||D^-1 b||
     HIPCHK(launch_edge_rhs(edge, X, PQ, nullptr, 1, partials, stream));
-    reduce_update(edge_rows_nwg(edge.nrows), STEP_TOL, opt.rtol, opt.atol);
+    reduce_update(edge.nwg, STEP_TOL, opt.rtol, opt.atol);
 
     int restarts = 0;
     uint64_t it_total = 0;

@@ -66,7 +66,8 @@ struct Smoother {
     bool fuse_pairs = false;
     // perimeter rows
     EdgeRowsDev edge;
-    std::vector<double> h_rhs;   // host copy of the static rhs (refilled on upload)
+    std::vector<double> h_rhs;   // host copy of the static rhs (refilled on upload), lp.rows order
+    std::vector<int32_t> order_all, order_nf, order_nf_g;   // run order of the three row tables (see build_table)
     double* d_rhs = nullptr;
     // relax mode: the perimeter rows that are not `fixed` (the only ones a sweep has to evaluate), and per owned block which
     // sides carry such rows
