@@ -47,6 +47,15 @@ typedef enum tm_error {
 const char* tm_last_error(void);
 int tm_abi_version(void);
 
+/* The reference logs two lines per outer iteration (std.log scope .smoothing): "iteration: {n}" before the fill and
+ * "\tresidual: {(sum dx^2 + sum dy^2)^2}" after the solve (reference src/core/smoothing/smooth.zig:105, 136-137).  A caller
+ * that wants them installs a sink: what = 0 announces iteration `iteration`, what = 1 carries its residual in `value`.
+ * Process-wide like the reference's logger; NULL (the default) switches it off.  With a sink installed every outer
+ * iteration ends with a reduction and a host round trip -- in TM_INNER_RELAX mode (one sweep = one outer iteration)
+ * that means one sweep per kernel pass and one synchronisation per sweep, so install it for diagnosis, not for speed. */
+typedef void (*tm_log_fn)(void* ctx, int32_t what, uint64_t iteration, double value);
+void tm_set_log(tm_log_fn sink, void* ctx);
+
 /* ------------------------------------------------------------------ data model
  * POD mirrors of the reference types, enum values in declaration order. */
 enum { TM_SIDE_I_MIN = 0, TM_SIDE_I_MAX = 1, TM_SIDE_J_MIN = 2, TM_SIDE_J_MAX = 3 };   /* boundary.zig:8-13   */
@@ -160,6 +169,22 @@ int tm_tfi_linear2d(double* xy_out, uint64_t ni, uint64_t nj,
  * Mutates mesh->blocks[b].xy in place.  iterations == 0 is legal and leaves the mesh untouched. */
 int tm_smooth_mesh(const tm_mesh_desc* mesh, uint64_t iterations, const tm_solver_opt* opt,
                    const tm_control_fn* cf, tm_stats* stats /* may be NULL */);
+
+/* ------------------------------------------------------------------ seam 2: the linear-solver slot
+ * Replaces a backend of solver.Solver (reference src/core/smoothing/solver.zig:40-93; pattern umfpack.zig:18-55): the
+ * caller has ASSEMBLED RowCompressedMatrixSystem2d (smooth.zig:277-307) and hands over its CSR arrays -- Ap = lhs_p[n+1],
+ * Ai = lhs_i, values = lhs_values -- with both right-hand sides and the solution vectors x_new / y_new, which carry the
+ * initial guess in and the solution out (warm start, BiCGStab.zig:136-153).  The x- and the y-system share the pattern and
+ * differ in the two entries of every sliding row (system.fillXSpecific / fillYSpecific, smooth.zig:1115-1165): pass the
+ * values after fillXSpecific as Ax_x and a copy taken after fillYSpecific as Ax_y (NULL = same values for both; exact
+ * whenever the mesh has no inlet / outlet condition).  Both components are solved together on the device by BiCGStab
+ * on D^-1 A with the stop test of tm_solver_opt (rtol, atol, max_inner, check_every; opt may be NULL = defaults).
+ * Returns TM_OK, TM_W_NOT_CONVERGED (warning, like BiCGStab.zig:368-369) or a negative error; host pointers throughout;
+ * the matrix is uploaded per call -- this is the faithful "reference-assembled, GPU-solved" mode, not the fast path
+ * (that is seam 1, which never assembles a matrix). */
+int tm_csr_solve(uint64_t n, const int32_t* Ap, const int32_t* Ai, const double* Ax_x, const double* Ax_y /* may be NULL */,
+                 const double* bx, const double* by, double* x /* in: guess, out */, double* y, const tm_solver_opt* opt /* may be NULL */,
+                 tm_stats* stats /* may be NULL */);
 
 /* ------------------------------------------------------------------ persistent handle
  * Same smoother with the coordinates resident in HBM between calls (for callers that iterate,

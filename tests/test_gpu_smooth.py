@@ -161,3 +161,31 @@ def test_full_size_sweep_properties():
         st2 = sm.iterate(20)
         assert 0 < st2["last_residual"] < st1["last_residual"]
         assert st2["operator_sweeps"] == 20
+
+
+def test_per_iteration_log_lines_like_the_reference(caplog):
+    # smooth.zig:105, 136-137: "iteration: n" and "\tresidual: r" per outer iteration; relax mode with a sink = one sweep per pass,
+    # same coordinates as the unlogged (two sweeps per pass) run
+    import logging
+
+    mesh = TOPOLOGIES["strip3_reversed"]()
+    om = OracleMesh(mesh)
+    hist, _ = oracle.picard_exact(om, 3)
+    with caplog.at_level(logging.INFO, logger="smoothing"):
+        smooth.mesh(mesh, 3, solver.Option.hip(rtol=1e-13))
+    msgs = [r.getMessage() for r in caplog.records if r.name == "smoothing"]
+    assert [m for m in msgs if m.startswith("iteration:")] == [f"iteration: {n}" for n in range(3)]
+    res = [float(m.split("residual:")[1]) for m in msgs if "residual:" in m]
+    assert res == pytest.approx(list(hist), rel=1e-5)
+    assert any(m.startswith("elapsed time for smoothing") for m in msgs)
+    a, b = configs.single_block(40, 70, perturb=0.2), configs.single_block(40, 70, perturb=0.2)
+    with smooth.Smoother(a, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+        sm.iterate(6)
+        sm.download()
+    caplog.clear()
+    with caplog.at_level(logging.INFO, logger="smoothing"), smooth.per_iteration_log(), smooth.Smoother(b, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+        sm.iterate(6)
+        sm.download()
+    assert np.array_equal(a.blocks[0].points.data, b.blocks[0].points.data)
+    res = [float(r.getMessage().split("residual:")[1]) for r in caplog.records if "residual:" in r.getMessage()]
+    assert len(res) == 6 and all(x > y > 0 for x, y in zip(res, res[1:]))

@@ -35,8 +35,11 @@ def test_harness_matches_oracle(tmp_path, args, builder):
     om = OracleMesh(builder())
     hist, _ = oracle.picard_exact(om, 3)
     assert float(np.sqrt(np.mean((got - om.flat()) ** 2))) <= 1e-10
-    logged = float(r.stdout.split("residual:")[1].split()[0])
-    assert logged == pytest.approx(hist[-1], rel=1e-6)
+    # the reference's two lines per outer iteration (smooth.zig:105, 136-137): every iteration announced, every residual logged
+    lines = r.stdout.splitlines()
+    assert [l for l in lines if "iteration:" in l] == [f"info(smoothing): iteration: {n}" for n in range(3)]
+    logged = [float(l.split("residual:")[1]) for l in lines if "residual:" in l]
+    assert len(logged) == 3 and logged == pytest.approx(list(hist), rel=1e-6)
 
 
 @pytest.mark.gpu

@@ -77,6 +77,9 @@ ALLREDUCE_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_
 EXCHANGE_WAIT_FN = C.CFUNCTYPE(C.c_int, C.c_void_p, C.c_void_p)
 
 
+LOG_FN = C.CFUNCTYPE(None, C.c_void_p, C.c_int32, C.c_uint64, C.c_double)
+
+
 class tm_comm_hooks(C.Structure):
     _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int32), ("nranks", C.c_int32), ("owner", C.POINTER(C.c_int32)),
                 ("exchange", EXCHANGE_FN), ("allreduce_sum", ALLREDUCE_FN), ("exchange_wait", EXCHANGE_WAIT_FN), ("workspace", C.c_void_p),
@@ -101,7 +104,7 @@ class tm_plan_local_info(C.Structure):
 
 # every symbol include/tm_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
-    "tm_last_error", "tm_abi_version", "tm_tfi_block", "tm_tfi_linear2d", "tm_smooth_mesh", "tm_smoother_create",
+    "tm_last_error", "tm_abi_version", "tm_set_log", "tm_csr_solve", "tm_tfi_block", "tm_tfi_linear2d", "tm_smooth_mesh", "tm_smoother_create",
     "tm_smoother_workspace_bytes", "tm_smoother_iterate", "tm_smoother_iterate_until", "tm_smoother_download", "tm_smoother_upload", "tm_smoother_destroy",
     "tm_smoother_exchange_plan", "tm_smoother_apply", "tm_smoother_rhs", "tm_smoother_row_kinds", "tm_smoother_dof",
     "tm_smoother_control_function", "tm_smoother_profile", "tm_smoother_profile_read", "tm_plan_build", "tm_plan_free", "tm_plan_local", "tm_plan_local_free", "tm_dev_tfi_block", "tm_dev_relax_sweep",
@@ -145,6 +148,10 @@ def lib():
         _share_hip_runtime()
         L = C.CDLL(LIB_PATH)
         L.tm_last_error.restype = C.c_char_p
+        L.tm_csr_solve.argtypes = [C.c_uint64, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, _dp, _dp, _dp, _dp, C.POINTER(tm_solver_opt),
+                                   C.POINTER(tm_stats)]
+        L.tm_set_log.argtypes = [LOG_FN, C.c_void_p]
+        L.tm_set_log.restype = None
         L.tm_smoother_dof.restype = C.c_uint64
         L.tm_smoother_dof.argtypes = [C.c_void_p]
         L.tm_dev_relax_partials_needed.restype = C.c_uint64

@@ -49,6 +49,10 @@ extern "C" {
 
 const char* tm_last_error(void) { return g_last_error.c_str(); }
 int tm_abi_version(void) { return TM_HIP_ABI_VERSION; }
+void tm_set_log(tm_log_fn sink, void* ctx) {
+    g_log_sink = sink;
+    g_log_ctx = ctx;
+}
 
 // internal tuning knob used by the benchmark sweeps (not part of the drop-in surface)
 int tm_tune_apply(int rows_per_chunk, int unroll, int pipe, int nt) {

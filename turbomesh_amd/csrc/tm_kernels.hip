@@ -25,6 +25,7 @@
 // Workgroup ids are remapped so that every XCD (own L2) walks a contiguous range of
 // (row-chunk, strip) tiles: the halo lines shared by neighbouring tiles hit in that L2.
 #include "tm_kernels.h"
+#include "tm_devutil.hpp"
 #include <type_traits>
 
 namespace tmh {
@@ -63,32 +64,6 @@ __device__ __forceinline__ double2 lane_next0(double2 v) {
     r.z = __builtin_amdgcn_update_dpp(0, s.z, 0x130, 0xf, 0xf, true);
     r.w = __builtin_amdgcn_update_dpp(0, s.w, 0x130, 0xf, 0xf, true);
     return __builtin_bit_cast(double2, r);
-}
-
-__device__ __forceinline__ double wave_sum(double v) {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;   // valid in lane 0
-}
-
-// Per-workgroup partials: every lane holds acc[]; sums waves in fixed order -> deterministic.
-template <int NT>
-__device__ __forceinline__ void block_partials(double (&acc)[MAX_PARTIALS], double* dst) {
-    constexpr int NW = NT / 64;
-    __shared__ double sh[NW][MAX_PARTIALS];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-#pragma unroll
-    for (int k = 0; k < MAX_PARTIALS; ++k) {
-        const double s = wave_sum(acc[k]);
-        if (lane == 0) sh[wave][k] = s;
-    }
-    __syncthreads();
-    if (threadIdx.x < MAX_PARTIALS) {
-        double s = 0.0;
-#pragma unroll
-        for (int w = 0; w < NW; ++w) s += sh[w][threadIdx.x];
-        dst[threadIdx.x] = s;
-    }
 }
 
 // ------------------------------------------------------------------------------------------

@@ -20,6 +20,9 @@ void hip_check(hipError_t e, const char* what) {
 }
 #define HIPCHK(x) hip_check((x), #x)
 
+tm_log_fn g_log_sink = nullptr;
+void* g_log_ctx = nullptr;
+
 // ------------------------------------------------------------------ arena
 DeviceArena::~DeviceArena() {
     for (void* p : owned_) (void)hipFree(p);
@@ -849,13 +852,19 @@ void Smoother::iterate(uint64_t iterations, tm_stats* stats) {
     const auto t0 = std::chrono::steady_clock::now();
     tm_stats st;
     std::memset(&st, 0, sizeof(st));
-    if (opt.inner == TM_INNER_RELAX) {
+    const tm_log_fn sink = g_log_sink;
+    if (opt.inner == TM_INNER_RELAX && !sink) {
         relax_sweeps(iterations, st);
         st.outer_iterations = iterations;
     } else {
+        // smooth.zig:104-137: "iteration: n" before the fill, "\tresidual: ..." after the solve.  A relaxation sweep IS an
+        // outer iteration, so a sink makes every sweep end with its own reduction (one sweep per pass, see tm_set_log).
         for (uint64_t n = 0; n < iterations; ++n) {
-            st.not_converged += picard_bicgstab(st);
+            if (sink) sink(g_log_ctx, 0, n, 0.0);
+            if (opt.inner == TM_INNER_RELAX) relax_sweeps(1, st);
+            else st.not_converged += picard_bicgstab(st);
             st.outer_iterations += 1;
+            if (sink) sink(g_log_ctx, 1, n, st.last_residual);
         }
     }
     sync();
@@ -885,11 +894,14 @@ bool Smoother::iterate_until(uint64_t max_iterations, double tol, tm_stats* stat
         stop_tol = tol;
         try {
             while (true) {
+                const tm_log_fn sink = g_log_sink;
+                if (sink) sink(g_log_ctx, 0, st.outer_iterations, 0.0);
                 const int rc = picard_bicgstab(st);
                 if (rc == 2) {
                     reached = true;
                     break;
                 }
+                if (sink) sink(g_log_ctx, 1, st.outer_iterations, st.last_residual);
                 st.not_converged += rc;
                 st.outer_iterations += 1;
                 if (st.outer_iterations >= max_iterations) break;

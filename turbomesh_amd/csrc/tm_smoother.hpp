@@ -16,6 +16,9 @@ struct TmError : std::runtime_error {
     TmError(int c, const std::string& m) : std::runtime_error(m), code(c) {}
 };
 void hip_check(hipError_t e, const char* what);
+// per-iteration log sink (tm_set_log), process-wide like the reference's std.log
+extern tm_log_fn g_log_sink;
+extern void* g_log_ctx;
 
 // Bump allocator over either library-owned hipMalloc chunks or a caller-provided workspace.
 class DeviceArena {

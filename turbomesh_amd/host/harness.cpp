@@ -122,6 +122,11 @@ int main(int argc, char** argv) {
             plot3d = argv[a + 1];
             a += 2;
         }
+        // the reference's two log lines per outer iteration (smooth.zig:105, 136-137)
+        tm_set_log([](void*, int32_t what, uint64_t n, double v) {
+            if (what == 0) std::printf("info(smoothing): iteration: %llu\n", static_cast<unsigned long long>(n));
+            else std::printf("info(smoothing): \tresidual: %.17g\n", v);
+        }, nullptr);
         tm_stats st{};
         if (until > 0.0 || !plot3d.empty()) {
             smoothing::smooth::Smoother sm(mesh, opt, smoothing::wall_control_function::Algorithm::laplace());
@@ -136,10 +141,8 @@ int main(int argc, char** argv) {
         } else {
             st = smoothing::smooth::mesh(mesh, iterations, opt, smoothing::wall_control_function::Algorithm::laplace());
         }
-        // the reference's log lines (smooth.zig:105, 137, 159)
-        std::printf("info(smoothing): iteration: %llu\n", static_cast<unsigned long long>(st.outer_iterations ? st.outer_iterations - 1 : 0));
-        std::printf("info(smoothing): \tresidual: %.17g\n", st.last_residual);
-        std::printf("info(smoothing): elapsed time for smoothing: %.2f s\n", st.seconds);
+        tm_set_log(nullptr, nullptr);
+        std::printf("info(smoothing): elapsed time for smoothing: %.2f s\n", st.seconds);   // smooth.zig:159
         std::printf("inner_iterations %llu operator_sweeps %llu not_converged %d scaled_residual_rms %.3e\n", static_cast<unsigned long long>(st.inner_iterations),
                     static_cast<unsigned long long>(st.operator_sweeps), st.not_converged, st.scaled_residual_rms);
         if (a < argc) {

@@ -16,18 +16,46 @@ from . import wall_control_function as _wcf
 log = logging.getLogger("smoothing")   # std.log.scoped(.smoothing), smooth.zig:58
 
 
+def _log_sink(ctx, what, iteration, value):
+    """The reference's two per-iteration lines (smooth.zig:105, 136-137) through Python's logging."""
+    if what == 0:
+        log.info("iteration: %d", iteration)
+    else:
+        log.info("\tresidual: %r", value)
+
+
+_LOG_CB = _capi.LOG_FN(_log_sink)   # kept alive for the lifetime of the module
+
+
+class per_iteration_log:
+    """Context manager: route the per-iteration lines of every smoother call inside it to logging ("smoothing" logger).
+    Costs one reduction + host round trip per outer iteration (see include/tm_hip.h tm_set_log)."""
+
+    def __init__(self, enable=True):
+        self.enable = enable
+
+    def __enter__(self):
+        if self.enable:
+            _capi.lib().tm_set_log(_LOG_CB, None)
+        return self
+
+    def __exit__(self, *exc):
+        if self.enable:
+            _capi.lib().tm_set_log(_capi.LOG_FN(), None)
+
+
 def mesh(mesh_data, iterations: int, solver_option: "_solver.Option | None" = None,
          control_function_algorithm: "_wcf.Algorithm | None" = None):
-    """smooth.zig:74-166: mutates mesh_data.blocks[b].points.data in place; returns the stats."""
+    """smooth.zig:74-166: mutates mesh_data.blocks[b].points.data in place; returns the stats.  Logs like the reference
+    ("iteration: n", "\tresidual: r" per outer iteration, then the elapsed time) when the `smoothing` logger is at INFO."""
     opt = (solver_option or _solver.Option.hip()).c_struct()
     cf = (control_function_algorithm or _wcf.Algorithm.laplace()).c_struct()
     md = _capi.MeshDesc(mesh_data)
     st = _capi.tm_stats()
-    rc = _capi.check(_capi.lib().tm_smooth_mesh(md.ref(), iterations, C.byref(opt), C.byref(cf), C.byref(st)))
+    with per_iteration_log(log.isEnabledFor(logging.INFO)):
+        rc = _capi.check(_capi.lib().tm_smooth_mesh(md.ref(), iterations, C.byref(opt), C.byref(cf), C.byref(st)))
     if rc == _capi.TM_W_NOT_CONVERGED:
         log.warning("hip solve did not converge in %d of %d outer iterations", st.not_converged, st.outer_iterations)
-    if iterations:
-        log.info("\tresidual: %r", st.last_residual)
     log.info("elapsed time for smoothing: %.2f s", st.seconds)
     return st.as_dict()
 

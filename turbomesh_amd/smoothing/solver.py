@@ -56,3 +56,47 @@ class Option:
     def c_struct(self):
         return _capi.tm_solver_opt(int(self.tag), int(self.inner), self.rtol, self.atol, self.max_inner, self.check_every,
                                    1 if self.single_sweep else 0, self.omega)
+
+
+class Solver:
+    """solver.zig:29-93 for the `hip` tag: holds the assembled system BY VALUE like the reference's backends (views of the
+    caller's arrays: lhs_p, lhs_i, lhs_values, rhs_x, rhs_y, x_new, y_new -- smooth.zig:277-307) and solves both components on
+    the MI355X through tm_csr_solve (seam 2).  `system` is any object with those attributes plus fillXSpecific() / fillYSpecific()
+    (smooth.zig:1115-1165); like umfpack.zig:18-24 they are called before the respective values are taken."""
+
+    def __init__(self, option: Option, system):
+        if option.tag != Tag.hip:
+            raise _capi.TmError(_capi.TM_E_UNSUPPORTED, "ExternalSolverNotEnabled: only the `hip` solver is built in (solver.zig:48, 56)")
+        self.option = option
+        self.system = system
+        self.stats = None
+
+    @classmethod
+    def init(cls, option: Option, system) -> "Solver":
+        return cls(option, system)
+
+    def deinit(self):
+        self.system = None
+
+    def solve(self):
+        import ctypes as C
+
+        import numpy as np
+
+        s = self.system
+        s.fillXSpecific()
+        ax_x = np.array(s.lhs_values, dtype=np.float64, copy=True)
+        s.fillYSpecific()
+        ax_y = np.ascontiguousarray(s.lhs_values, dtype=np.float64)
+        p = np.ascontiguousarray(s.lhs_p, dtype=np.int32)
+        i = np.ascontiguousarray(s.lhs_i, dtype=np.int32)
+        n = len(p) - 1
+        ip = C.POINTER(C.c_int32)
+        opt = self.option.c_struct()
+        st = _capi.tm_stats()
+        for v in (s.rhs_x, s.rhs_y, s.x_new, s.y_new):
+            assert v.dtype == np.float64 and v.flags["C_CONTIGUOUS"] and len(v) == n
+        rc = _capi.check(_capi.lib().tm_csr_solve(n, p.ctypes.data_as(ip), i.ctypes.data_as(ip), _capi.f64ptr(ax_x), _capi.f64ptr(ax_y), _capi.f64ptr(s.rhs_x),
+                                                  _capi.f64ptr(s.rhs_y), _capi.f64ptr(s.x_new), _capi.f64ptr(s.y_new), C.byref(opt), C.byref(st)))
+        self.stats = st.as_dict()
+        return rc == 0
