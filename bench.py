@@ -164,11 +164,13 @@ def solve_to_tolerance(n, smooth, solver, configs, tol=1e-8):
     config 2, displacement 0.25 h, seed 12345) driven to a scaled nonlinear residual <= 1e-8 by Picard + multigrid-preconditioned
     BiCGStab.  Reported beside the headline metric, outside its timed region."""
     mesh = configs.single_block(n, n, perturb=0.25)
-    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-10, check_every=2)) as sm:
+    # inexact Picard: the inner tolerance only has to carry the NONLINEAR residual below `tol` (tools/solve_probe.py: rtol 1e-6
+    # reaches it in one outer iteration with 2 inner iterations; 1e-10 needs 5 for the same residual, 1e-4 stalls above it)
+    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-6, check_every=1)) as sm:
         reached, st = sm.iterate_until(tol, 50)
     return {"reached": bool(reached), "tolerance": tol, "outer_iterations": st["outer_iterations"], "inner_iterations": st["inner_iterations"],
             "operator_sweeps": st["operator_sweeps"], "seconds": st["seconds"], "scaled_residual_rms": st["scaled_residual_rms"],
-            "solver": "hip/mg_bicgstab (Picard + BiCGStab, one multigrid V(2,2) cycle per block as preconditioner)"}
+            "inner_rtol": 1e-6, "solver": "hip/mg_bicgstab (Picard + BiCGStab, one multigrid V(2,2) cycle per block as preconditioner)"}
 
 
 def self_launch(args):

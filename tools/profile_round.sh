@@ -1,0 +1,24 @@
+#!/bin/bash
+# Collects the profiles a round commits under profiles/ (run on the MI355X box through gpurun, from the repo root):
+#   usage: tools/profile_round.sh r02
+# kernel-trace + stats of the bench command (two sweeps per pass, and --single-sweep), of the Krylov and multigrid paths, and the
+# two SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with tracing domains) that profiles/traffic.json is made from.
+set -u
+tag=${1:-r02}
+root=${GRAFT_REPO_ROOT:-$(pwd)}
+out=$root/gpurun_out/prof_$tag
+mkdir -p "$out"
+cd /tmp && export TMPDIR=/tmp
+prof() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d "$out/$name" -o p -- "$@" > "$out/$name.out" 2> "$out/$name.err"; cp "$out/$name"/p_kernel_stats.csv "$out/${tag}_${name}_kernel_stats.csv" 2>/dev/null; }
+prof bench4096_k2x2 python3 "$root/bench.py" --no-cpu-baseline --no-solve
+prof bench4096_k2_single python3 "$root/bench.py" --no-cpu-baseline --no-solve --single-sweep
+prof bicgstab4096 python3 "$root/tools/prof_sweep.py" 4096 24 bicgstab
+prof mg_solve4096 python3 "$root/tools/solve_probe.py" 4096
+prof config4_8x2048 python3 "$root/bench.py" --config 4 --no-cpu-baseline --steps 100
+rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o p -- python3 "$root/tools/prof_sweep.py" 4096 20 relax > /dev/null 2>&1
+rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o p -- python3 "$root/tools/prof_sweep.py" 4096 20 relax > /dev/null 2>&1
+cp "$out"/pmc_fetch/p_counter_collection.csv "$out/${tag}_pmc_fetch_counter_collection.csv" 2>/dev/null
+cp "$out"/pmc_write/p_counter_collection.csv "$out/${tag}_pmc_write_counter_collection.csv" 2>/dev/null
+cd "$root"
+grep -h '^{' "$out/bench4096_k2x2.out" > "$out/${tag}_bench_n1_under_rocprof.json"
+ls "$out"

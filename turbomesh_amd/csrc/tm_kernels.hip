@@ -1333,12 +1333,33 @@ hipError_t launch_scalar_update(KrylovScalars* S, const double* red, int step, h
     return hipGetLastError();
 }
 
+// The vector kernels stream 3-7 arrays far larger than the caches (256 MiB each at 4096^2) and re-use nothing: every thread
+// takes VEC_UNROLL elements per trip with all their loads issued before the first use (more requests in flight per wave), loads
+// and stores are non-temporal.
+constexpr int VEC_UNROLL = 2;
+__device__ __forceinline__ double2 load_nt(const double2* src) {
+    const d2v v = __builtin_nontemporal_load(reinterpret_cast<const d2v*>(src));
+    return make_double2(v.x, v.y);
+}
+
 __global__ __launch_bounds__(VEC_BLOCK) void k_p_update(const KrylovScalars* __restrict__ S, const double2* __restrict__ r,
                                                         double2* __restrict__ p, const double2* __restrict__ v, int64_t n) {
     const double bx = S->beta[0], by = S->beta[1], ox = S->omega[0], oy = S->omega[1];
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * VEC_BLOCK) {
-        const double2 ri = r[i], pi = p[i], vi = v[i];
-        store_nt(p + i, make_double2(ri.x + bx * (pi.x - ox * vi.x), ri.y + by * (pi.y - oy * vi.y)));   // BiCGStab.zig:310-312
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * VEC_BLOCK;
+    for (int64_t i0 = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i0 < n; i0 += stride * VEC_UNROLL) {
+        double2 ri[VEC_UNROLL], pi[VEC_UNROLL], vi[VEC_UNROLL];
+#pragma unroll
+        for (int q = 0; q < VEC_UNROLL; ++q) {
+            const int64_t i = min(i0 + q * stride, n - 1);
+            ri[q] = load_nt(r + i);
+            pi[q] = load_nt(p + i);
+            vi[q] = load_nt(v + i);
+        }
+#pragma unroll
+        for (int q = 0; q < VEC_UNROLL; ++q) {
+            const int64_t i = i0 + q * stride;
+            if (i < n) store_nt(p + i, make_double2(ri[q].x + bx * (pi[q].x - ox * vi[q].x), ri[q].y + by * (pi[q].y - oy * vi[q].y)));   // BiCGStab.zig:310-312
+        }
     }
 }
 hipError_t launch_p_update(const KrylovScalars* S, const double2* r, double2* p, const double2* v, int64_t n, hipStream_t st) {
@@ -1351,12 +1372,25 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_s_update(const KrylovScalars* __r
                                                         double* partials) {
     const double ax = S->alpha[0], ay = S->alpha[1];
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * VEC_BLOCK) {
-        const double2 ri = r[i], vi = v[i];
-        const double2 si = make_double2(ri.x - ax * vi.x, ri.y - ay * vi.y);   // BiCGStab.zig:325-327
-        store_nt(s + i, si);
-        acc[0] += si.x * si.x;
-        acc[1] += si.y * si.y;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * VEC_BLOCK;
+    for (int64_t i0 = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i0 < n; i0 += stride * VEC_UNROLL) {
+        double2 ri[VEC_UNROLL], vi[VEC_UNROLL];
+#pragma unroll
+        for (int q = 0; q < VEC_UNROLL; ++q) {
+            const int64_t i = min(i0 + q * stride, n - 1);
+            ri[q] = load_nt(r + i);
+            vi[q] = load_nt(v + i);
+        }
+#pragma unroll
+        for (int q = 0; q < VEC_UNROLL; ++q) {
+            const int64_t i = i0 + q * stride;
+            if (i < n) {
+                const double2 si = make_double2(ri[q].x - ax * vi[q].x, ri[q].y - ay * vi[q].y);   // BiCGStab.zig:325-327
+                store_nt(s + i, si);
+                acc[0] += si.x * si.x;
+                acc[1] += si.y * si.y;
+            }
+        }
     }
     block_partials<VEC_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
@@ -1371,20 +1405,38 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_xr_update(const KrylovScalars* __
                                                          const double2* __restrict__ r_hat, int64_t n, double* partials) {
     const double ax = S->alpha[0], ay = S->alpha[1], ox = S->omega[0], oy = S->omega[1];
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * VEC_BLOCK) {
-        const double2 pi = p_hat[i], sh = s_hat[i], si = s[i], ti = t[i], rh = r_hat[i];
-        double2 ui = u[i];
-        ui.x += ax * pi.x;   // BiCGStab.zig:329-331 (x += alpha * p_hat)
-        ui.y += ay * pi.y;
-        ui.x += ox * sh.x;   // BiCGStab.zig:352-354 (x += omega * s_hat)
-        ui.y += oy * sh.y;
-        store_nt(u + i, ui);
-        const double2 ri = make_double2(si.x - ox * ti.x, si.y - oy * ti.y);   // BiCGStab.zig:356-358
-        store_nt(r + i, ri);
-        acc[0] += rh.x * ri.x;
-        acc[1] += rh.y * ri.y;
-        acc[2] += ri.x * ri.x;
-        acc[3] += ri.y * ri.y;
+    const bool plain = (s_hat == s);   // no preconditioner: one stream less
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * VEC_BLOCK;
+    for (int64_t i0 = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i0 < n; i0 += stride * VEC_UNROLL) {
+        double2 pi[VEC_UNROLL], sh[VEC_UNROLL], si[VEC_UNROLL], ti[VEC_UNROLL], rh[VEC_UNROLL], ui[VEC_UNROLL];
+#pragma unroll
+        for (int q = 0; q < VEC_UNROLL; ++q) {
+            const int64_t i = min(i0 + q * stride, n - 1);
+            pi[q] = load_nt(p_hat + i);
+            si[q] = load_nt(s + i);
+            sh[q] = plain ? si[q] : load_nt(s_hat + i);
+            ti[q] = load_nt(t + i);
+            rh[q] = load_nt(r_hat + i);
+            ui[q] = load_nt(u + i);
+        }
+#pragma unroll
+        for (int q = 0; q < VEC_UNROLL; ++q) {
+            const int64_t i = i0 + q * stride;
+            if (i < n) {
+                double2 un = ui[q];
+                un.x += ax * pi[q].x;   // BiCGStab.zig:329-331 (x += alpha * p_hat)
+                un.y += ay * pi[q].y;
+                un.x += ox * sh[q].x;   // BiCGStab.zig:352-354 (x += omega * s_hat)
+                un.y += oy * sh[q].y;
+                store_nt(u + i, un);
+                const double2 ri = make_double2(si[q].x - ox * ti[q].x, si[q].y - oy * ti[q].y);   // BiCGStab.zig:356-358
+                store_nt(r + i, ri);
+                acc[0] += rh[q].x * ri.x;
+                acc[1] += rh[q].y * ri.y;
+                acc[2] += ri.x * ri.x;
+                acc[3] += ri.y * ri.y;
+            }
+        }
     }
     block_partials<VEC_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
@@ -1399,12 +1451,25 @@ hipError_t launch_xr_update(const KrylovScalars* S, double2* u, const double2* p
 __global__ __launch_bounds__(VEC_BLOCK) void k_residual_copyback(double2* __restrict__ xk, const double2* __restrict__ u, int64_t n,
                                                                  double* partials) {
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
-    for (int64_t i = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * VEC_BLOCK) {
-        const double2 a = xk[i], b = u[i];
-        const double dx = a.x - b.x, dy = a.y - b.y;
-        acc[0] += dx * dx;
-        acc[1] += dy * dy;
-        xk[i] = b;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * VEC_BLOCK;
+    for (int64_t i0 = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i0 < n; i0 += stride * VEC_UNROLL) {
+        double2 a[VEC_UNROLL], b[VEC_UNROLL];
+#pragma unroll
+        for (int q = 0; q < VEC_UNROLL; ++q) {
+            const int64_t i = min(i0 + q * stride, n - 1);
+            a[q] = load_nt(xk + i);
+            b[q] = load_nt(u + i);
+        }
+#pragma unroll
+        for (int q = 0; q < VEC_UNROLL; ++q) {
+            const int64_t i = i0 + q * stride;
+            if (i < n) {
+                const double dx = a[q].x - b[q].x, dy = a[q].y - b[q].y;
+                acc[0] += dx * dx;
+                acc[1] += dy * dy;
+                store_nt(xk + i, b[q]);
+            }
+        }
     }
     block_partials<VEC_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
