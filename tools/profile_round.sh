@@ -13,12 +13,13 @@ prof() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d
 prof bench4096_k2x2 python3 "$root/bench.py" --no-cpu-baseline --no-solve
 prof bench4096_k2_single python3 "$root/bench.py" --no-cpu-baseline --no-solve --single-sweep
 prof bicgstab4096 python3 "$root/tools/prof_sweep.py" 4096 24 bicgstab
-prof mg_solve4096 python3 "$root/tools/solve_probe.py" 4096
+prof mg_solve4096 python3 "$root/tools/solve_probe.py" 4096 1e-6
 prof config4_8x2048 python3 "$root/bench.py" --config 4 --no-cpu-baseline --steps 100
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o p -- python3 "$root/tools/prof_sweep.py" 4096 20 relax > /dev/null 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o p -- python3 "$root/tools/prof_sweep.py" 4096 20 relax > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o p -- python3 "$root/tools/prof_sweep.py" 4096 20 relax > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o p -- python3 "$root/tools/prof_sweep.py" 4096 20 relax > /dev/null 2>&1
 cp "$out"/pmc_fetch/p_counter_collection.csv "$out/${tag}_pmc_fetch_counter_collection.csv" 2>/dev/null
 cp "$out"/pmc_write/p_counter_collection.csv "$out/${tag}_pmc_write_counter_collection.csv" 2>/dev/null
 cd "$root"
+python3 tools/pmc_traffic.py "$out/pmc_fetch" "$out/pmc_write" 4096 "$out/traffic.json" > /dev/null
 grep -h '^{' "$out/bench4096_k2x2.out" > "$out/${tag}_bench_n1_under_rocprof.json"
 ls "$out"

@@ -5,7 +5,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from turbomesh_amd import configs
 from turbomesh_amd.smoothing import smooth, solver
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-for rtol in (1e-10, 1e-6, 1e-4, 1e-3, 1e-2):
+rtols = [float(a) for a in sys.argv[2:]] or [1e-10, 1e-6, 1e-4, 1e-3, 1e-2]
+for rtol in rtols:
     mesh = configs.single_block(n, n, perturb=0.25)
     with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=rtol)) as sm:
         reached, st = sm.iterate_until(1e-8, 50)
