@@ -1201,6 +1201,34 @@ hipError_t launch_edge_rhs(const EdgeRowsDev& e, const double2* xk, const double
 }
 
 // ------------------------------------------------------------------------------------------
+// queue-to-queue ordering through device memory (see Smoother::relax_pairs_pipelined)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(64) void k_queue_signal(uint32_t* counter) {
+    // the kernels before this one in the queue have completed (in-order queue, end-of-kernel release); publish at agent scope
+    if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+__global__ __launch_bounds__(64) void k_queue_wait(const uint32_t* counter, uint32_t target, uint32_t* error) {
+    if (threadIdx.x != 0) return;
+    unsigned polls = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++polls > (1u << 22)) {   // ~1 s: fail the pass rather than hang the device
+            __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+    // the kernels behind this one start with the usual start-of-kernel acquire: they see what the signalling queue had completed
+}
+hipError_t launch_queue_signal(uint32_t* counter, hipStream_t st) {
+    hipLaunchKernelGGL(k_queue_signal, dim3(1), dim3(64), 0, st, counter);
+    return hipGetLastError();
+}
+hipError_t launch_queue_wait(const uint32_t* counter, uint32_t target, uint32_t* error, hipStream_t st) {
+    hipLaunchKernelGGL(k_queue_wait, dim3(1), dim3(64), 0, st, counter, target, error);
+    return hipGetLastError();
+}
+
+// ------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partials, int nwg, double* __restrict__ red) {

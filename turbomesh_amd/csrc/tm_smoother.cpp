@@ -9,8 +9,10 @@
 //   TM_INNER_RELAX     every outer iteration is one fused Jacobi sweep of the nonlinear system.
 #include "tm_smoother.hpp"
 #include <algorithm>
+#include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 
 namespace tmh {
@@ -20,6 +22,7 @@ void hip_check(hipError_t e, const char* what) {
 }
 #define HIPCHK(x) hip_check((x), #x)
 
+std::atomic<int> g_multirank_handles{0};
 tm_log_fn g_log_sink = nullptr;
 void* g_log_ctx = nullptr;
 
@@ -115,8 +118,10 @@ void Smoother::sync() { HIPCHK(hipStreamSynchronize(stream)); }
 
 // Everything the handle owns outside the arena; also runs when create() throws half-way (pinned buffers already allocated).
 Smoother::~Smoother() {
+    if (counted) g_multirank_handles.fetch_sub(1);
     if (h_S) (void)hipHostFree(h_S);
     if (h_red) (void)hipHostFree(h_red);
+    if (h_flags) (void)hipHostFree(h_flags);
     for (hipEvent_t e : ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_stop) (void)hipEventDestroy(e);
     if (side) {
@@ -165,6 +170,10 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         lp = build_local_plan(topo, all_rows, owner, rank, nranks);
     } catch (const PlanError& e) {
         throw TmError(e.code, e.what());
+    }
+    if (has_hooks && !measure && !counted) {
+        counted = true;
+        g_multirank_handles.fetch_add(1);
     }
     n_owned = lp.n_owned;
     n_ghost = static_cast<int64_t>(lp.ghost_gid.size());
@@ -361,10 +370,13 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         while (pr.gid < topo.start[b]) --b;
         const size_t kb = std::lower_bound(lp.owned_blocks.begin(), lp.owned_blocks.end(), b) - lp.owned_blocks.begin();
         const int64_t flat = pr.gid - topo.start[b], bi = flat / topo.nj[b], bj = flat % topo.nj[b];
+        // a corner node counts for its ROW only (the tiles along that row include the corner tile): the end points of an interface
+        // along i = 0 must not turn the two side walls into sides whose workgroups wait for the perimeter-row pass
+        const bool corner_row = bi == 0 || bi == topo.ni[b] - 1;
         if (bi == 0) dyn_mask[kb] |= 1;
         if (bi == topo.ni[b] - 1) dyn_mask[kb] |= 2;
-        if (bj == 0) dyn_mask[kb] |= 4;
-        if (bj == topo.nj[b] - 1) dyn_mask[kb] |= 8;
+        if (bj == 0 && !corner_row) dyn_mask[kb] |= 4;
+        if (bj == topo.nj[b] - 1 && !corner_row) dyn_mask[kb] |= 8;
     }
     if (opt.inner == TM_INNER_RELAX) {
         std::vector<const PlanRow*> sel;
@@ -407,6 +419,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     partials = arena.alloc_n<double>(static_cast<uint64_t>(std::max(std::max(nwg_apply, nwg_apply2), nwg_vec)) * MAX_PARTIALS);
     red = arena.alloc_n<double>(MAX_PARTIALS);
     S = arena.alloc_n<KrylovScalars>(1);
+    sync_flags = arena.alloc_n<uint32_t>(64);   // [0] border passes done, [1] interior passes done, [2] a wait timed out
 
     // ---- halo exchange
     n_send = static_cast<int64_t>(lp.send_ids.size());
@@ -419,6 +432,8 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_S), sizeof(KrylovScalars), hipHostMallocDefault));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_red), sizeof(double) * MAX_PARTIALS, hipHostMallocDefault));
     HIPCHK(hipMemsetAsync(S, 0, sizeof(KrylovScalars), stream));
+    HIPCHK(hipMemsetAsync(sync_flags, 0, sizeof(uint32_t) * 64, stream));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_flags), sizeof(uint32_t) * 4, hipHostMallocDefault));
     for (double2* q : {p_hat, s_hat, mg_w0, mg_w1})
         if (q) HIPCHK(hipMemsetAsync(q, 0, sizeof(double2) * n_local, stream));
     if (PQ) HIPCHK(hipMemsetAsync(PQ, 0, sizeof(double2) * n_local, stream));
@@ -776,6 +791,40 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
         HIPCHK(hipEventCreateWithFlags(&ev_inside[0], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_inside[1], hipEventDisableTiming));
     }
+    // Ordering between the two queues INSIDE the loop.  hipEventRecord / hipStreamWaitEvent are barrier packets, and every one of
+    // them stalls its queue for 7-12 us on this part (rocprofv3 traces under profiles/): 10 % of a 4096^2 pass on the handle's
+    // stream, a fifth of the chain of a 2048^2 pass.  So a dependency is a one-wave kernel on either side instead: the producer queue
+    // runs k_queue_signal behind the producing kernel (bumps a counter in device memory), the consumer queue runs k_queue_wait in
+    // front of the consuming one (spins, with sleeps, until the counter has reached its target; kernel boundaries inside a queue
+    // cost well under a microsecond).  A waiter's producer is always enqueued before it, in host order, so the pair cannot
+    // deadlock even if both streams share a hardware queue; a wait that is not met within ~1 s raises sync_flags[2] and the pass
+    // fails with TM_E_HIP instead of hanging the device.  Several multi-rank handles in ONE process (the virtual-rank tests) could
+    // block each other through shared hardware queues: they use events.
+    static const bool events_env = [] { const char* e = std::getenv("TM_PAIR_SYNC"); return e && std::strcmp(e, "events") == 0; }();
+    const bool use_flags = !events_env && g_multirank_handles.load() <= 1;
+    uint32_t* border_done = sync_flags;
+    uint32_t* inside_done = sync_flags + 1;
+    uint32_t* sync_err = sync_flags + 2;
+    uint32_t n_border = 0, n_inside = 0;   // signals sent so far
+    if (use_flags) HIPCHK(hipMemsetAsync(sync_flags, 0, sizeof(uint32_t) * 4, stream));
+    auto signal_border = [&]() {   // on side, behind the border pass
+        if (use_flags) HIPCHK(launch_queue_signal(border_done, side));
+        else HIPCHK(hipEventRecord(ev_to_main, side));
+        n_border += 1;
+    };
+    auto wait_border = [&]() {     // on the handle's stream, in front of the interior pass
+        if (use_flags) HIPCHK(launch_queue_wait(border_done, n_border, sync_err, stream));
+        else HIPCHK(hipStreamWaitEvent(stream, ev_to_main, 0));
+    };
+    auto signal_inside = [&]() {   // on the handle's stream, behind the interior pass
+        if (use_flags) HIPCHK(launch_queue_signal(inside_done, stream));
+        else HIPCHK(hipEventRecord(ev_inside[n_inside & 1], stream));
+        n_inside += 1;
+    };
+    auto wait_inside = [&](uint32_t upto) {   // on side, in front of the border pass: interior passes 0 .. upto-1 are done
+        if (use_flags) HIPCHK(launch_queue_wait(inside_done, upto, sync_err, side));
+        else HIPCHK(hipStreamWaitEvent(side, ev_inside[(upto - 1) & 1], 0));
+    };
     const EdgeRowsDev& e1 = edge_nf_g.nrows ? edge_nf_g : edge_nf;
     auto edge_on_side = [&](const EdgeRowsDev& e, const double2* in, double2* out, int dot) {
         HIPCHK(launch_edge_rows(e, in, in, PQ, nullptr, out, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, side));
@@ -790,10 +839,10 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
     exchange_on_side(X);
     edge_on_side(e1, X, M, DOT_NONE);    // E1g(0): perimeter rows (own + ghost) of the intermediate field
     relax2_launch(R2_INSIDE, false, dot);
-    HIPCHK(hipEventRecord(ev_inside[0], stream));
+    signal_inside();
     relax2_launch(R2_BORDER, true, dot, side);
     for (uint64_t k = 0; k < npairs; ++k) {
-        HIPCHK(hipEventRecord(ev_to_main, side));   // the border workgroups of pair k are done
+        if (k + 1 < npairs) signal_border();          // the border workgroups of pair k are done
         edge_on_side(edge_nf, M, U, dot);             // E2(k): perimeter rows of the pair's output (ghost operands: M's ghost rows)
         std::swap(X, U);
         if (k + 1 == npairs) {
@@ -802,13 +851,17 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
         }
         // pair k+1: input = this pair's output
         dot = (k + 2 == npairs && want_partials_last) ? DOT_DELTA : DOT_NONE;
-        HIPCHK(hipStreamWaitEvent(stream, ev_to_main, 0));   // interior pass k+1 reads rows the border of pair k wrote, and overwrites its input
+        wait_border();                                // interior pass k+1 reads rows the border of pair k wrote, and overwrites its input
         relax2_launch(R2_INSIDE, false, dot);
-        HIPCHK(hipEventRecord(ev_inside[(k + 1) & 1], stream));
+        signal_inside();
         exchange_on_side(X);
         edge_on_side(e1, X, M, DOT_NONE);             // E1g(k+1)
-        HIPCHK(hipStreamWaitEvent(side, ev_inside[k & 1], 0));   // border k+1 reads rows interior pass k wrote, and overwrites ITS input
+        wait_inside(static_cast<uint32_t>(k + 1));    // border k+1 reads rows interior pass k wrote, and overwrites ITS input
         relax2_launch(R2_BORDER, true, dot, side);
+    }
+    if (use_flags) {
+        HIPCHK(hipMemcpyAsync(h_flags, sync_flags, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, stream));
+        flags_pending = true;
     }
 }
 
@@ -840,6 +893,10 @@ void Smoother::relax_sweeps(uint64_t n, tm_stats& st) {
         reduce(last_nwg);   // partial sums of the LAST sweep -> sum (x_old - x_new)^2, sum (y_old - y_new)^2
         HIPCHK(hipMemcpyAsync(h_red, red, sizeof(double) * MAX_PARTIALS, hipMemcpyDeviceToHost, stream));
         sync();
+        if (flags_pending) {
+            flags_pending = false;
+            if (h_flags[2] != 0) throw TmError(TM_E_HIP, "a device-side dependency between the interior and the border pass was not met within its time limit");
+        }
         st.last_dx2 = h_red[0];
         st.last_dy2 = h_red[1];
         st.last_residual = (h_red[0] + h_red[1]) * (h_red[0] + h_red[1]);

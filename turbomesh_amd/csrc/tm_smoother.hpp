@@ -4,6 +4,7 @@
 #include "tm_kernels.h"
 #include "tm_multigrid.hpp"
 #include "tm_plan.hpp"
+#include <atomic>
 #include <memory>
 #include <string>
 #include <functional>
@@ -17,6 +18,7 @@ struct TmError : std::runtime_error {
 };
 void hip_check(hipError_t e, const char* what);
 // per-iteration log sink (tm_set_log), process-wide like the reference's std.log
+extern std::atomic<int> g_multirank_handles;   // live handles with comm hooks in this process
 extern tm_log_fn g_log_sink;
 extern void* g_log_ctx;
 
@@ -131,6 +133,10 @@ struct Smoother {
     hipEvent_t ev_to_side = nullptr, ev_to_main = nullptr, ev_inside[2] = {nullptr, nullptr};
     void fence(hipStream_t from, hipStream_t to, hipEvent_t ev);
     void relax_pairs_pipelined(uint64_t npairs, bool want_partials_last);
+    uint32_t* sync_flags = nullptr;   // device counters of the cross-queue dependencies of a sweep pair (k_queue_signal / k_queue_wait)
+    uint32_t* h_flags = nullptr;      // pinned
+    bool flags_pending = false;
+    bool counted = false;             // this handle is one of g_multirank_handles
     bool exchange_pending = false;
     // step >= 0: the Krylov scalar update that consumes the fused dot products follows the reduction (one launch without hooks)
     void apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega, int step = -1);
