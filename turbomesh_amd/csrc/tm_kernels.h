@@ -133,6 +133,7 @@ hipError_t launch_edge_rhs(const EdgeRowsDev& e, const double2* xk, const double
 // its queue is complete and visible device-wide; wait: returns once *counter >= target (gives up after ~1 s and sets *error).
 hipError_t launch_queue_signal(uint32_t* counter, hipStream_t stream);
 hipError_t launch_queue_wait(const uint32_t* counter, uint32_t target, uint32_t* error, hipStream_t stream);
+hipError_t launch_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error, hipStream_t stream);
 
 // ---- reductions: sum partial rows [nwg][MAX_PARTIALS] in fixed order into red[MAX_PARTIALS]
 hipError_t launch_finalize(const double* partials, int nwg, double* red, hipStream_t stream);

@@ -1219,6 +1219,23 @@ __global__ __launch_bounds__(64) void k_queue_wait(const uint32_t* counter, uint
     }
     // the kernels behind this one start with the usual start-of-kernel acquire: they see what the signalling queue had completed
 }
+// both in one launch (a kernel boundary less on the handle's stream): announce what precedes, then wait for the other queue
+__global__ __launch_bounds__(64) void k_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error) {
+    if (threadIdx.x != 0) return;
+    __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    unsigned polls = 0;
+    while (__hip_atomic_load(other, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(8);
+        if (++polls > (1u << 22)) {
+            __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
+        }
+    }
+}
+hipError_t launch_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error, hipStream_t st) {
+    hipLaunchKernelGGL(k_queue_signal_wait, dim3(1), dim3(64), 0, st, counter, other, target, error);
+    return hipGetLastError();
+}
 hipError_t launch_queue_signal(uint32_t* counter, hipStream_t st) {
     hipLaunchKernelGGL(k_queue_signal, dim3(1), dim3(64), 0, st, counter);
     return hipGetLastError();

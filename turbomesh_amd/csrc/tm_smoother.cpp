@@ -839,7 +839,7 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
     exchange_on_side(X);
     edge_on_side(e1, X, M, DOT_NONE);    // E1g(0): perimeter rows (own + ghost) of the intermediate field
     relax2_launch(R2_INSIDE, false, dot);
-    signal_inside();
+    if (!use_flags || npairs == 1) signal_inside();   // with counters the announcement travels with the next wait (one launch)
     relax2_launch(R2_BORDER, true, dot, side);
     for (uint64_t k = 0; k < npairs; ++k) {
         if (k + 1 < npairs) signal_border();          // the border workgroups of pair k are done
@@ -851,9 +851,15 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
         }
         // pair k+1: input = this pair's output
         dot = (k + 2 == npairs && want_partials_last) ? DOT_DELTA : DOT_NONE;
-        wait_border();                                // interior pass k+1 reads rows the border of pair k wrote, and overwrites its input
+        // interior pass k+1 reads rows the border of pair k wrote, and overwrites its input
+        if (use_flags) {   // "interior pass k is done" + "wait for border k" in one launch; the last interior pass is announced on its own
+            HIPCHK(launch_queue_signal_wait(inside_done, border_done, n_border, sync_err, stream));
+            n_inside += 1;
+        } else {
+            wait_border();
+        }
         relax2_launch(R2_INSIDE, false, dot);
-        signal_inside();
+        if (!use_flags) signal_inside();
         exchange_on_side(X);
         edge_on_side(e1, X, M, DOT_NONE);             // E1g(k+1)
         wait_inside(static_cast<uint32_t>(k + 1));    // border k+1 reads rows interior pass k wrote, and overwrites ITS input
