@@ -120,8 +120,10 @@ enum {
 };
 /* tm_solver_opt.flags */
 enum {
-    TM_OPT_SINGLE_SWEEP = 1  /* TM_INNER_RELAX: one kernel pass per sweep.  Default (bit clear): sweeps are taken two per pass
+    TM_OPT_SINGLE_SWEEP = 1, /* TM_INNER_RELAX: one kernel pass per sweep.  Default (bit clear): sweeps are taken two per pass
                                 where the blocks allow it (same arithmetic, bit-identical coordinates, half the HBM traffic) */
+    TM_OPT_EAGER_SCALARS = 2 /* Krylov modes: every reduction gets its own scalar-update launch.  Default (bit clear): on small
+                                single-process meshes the update travels with the kernel that consumes it (same sums, same order) */
 };
 typedef struct tm_solver_opt {
     int32_t tag;             /* TM_SOLVER_* */

@@ -189,3 +189,21 @@ def test_per_iteration_log_lines_like_the_reference(caplog):
     assert np.array_equal(a.blocks[0].points.data, b.blocks[0].points.data)
     res = [float(r.getMessage().split("residual:")[1]) for r in caplog.records if "residual:" in r.getMessage()]
     assert len(res) == 6 and all(x > y > 0 for x, y in zip(res, res[1:]))
+
+
+@pytest.mark.parametrize("name", ["two_by_two_junction", "strip3_reversed", "plate_le"])
+@pytest.mark.parametrize("inner", [solver.Inner.bicgstab, solver.Inner.mg_bicgstab])
+def test_small_mesh_launch_savings_do_not_change_a_bit(name, inner):
+    # small single-process meshes: interior + perimeter rows in one launch, scalar steps folded into the kernels that consume them
+    # (LazyScalars) -- same sums in the same order, so the iterates equal those of the launch-per-step path bit for bit
+    control = wcf.Algorithm(wcf.White(0.02)) if name == "plate_le" else None
+    out = []
+    for eager in (True, False):
+        mesh = TOPOLOGIES[name]()
+        with smooth.Smoother(mesh, solver.Option.hip(inner=inner, rtol=1e-12, max_inner=3000, eager_scalars=eager), control) as sm:
+            st = sm.iterate(3)
+            sm.download()
+        out.append((mesh_flat(mesh), st))
+    assert out[0][1]["not_converged"] == 0
+    assert out[0][1]["inner_iterations"] == out[1][1]["inner_iterations"]
+    assert np.array_equal(out[0][0], out[1][0])

@@ -215,16 +215,16 @@ extern "C" int tm_csr_solve(uint64_t n64, const int32_t* Ap, const int32_t* Ai, 
             }
             bool breakdown = false;
             while (it_total < opt.max_inner) {
-                HIPCHK(launch_p_update(S, r, p, v, n, st));
+                HIPCHK(launch_p_update(plain_scalars(S), r, p, v, n, st));
                 hipLaunchKernelGGL((k_csr_apply<false, DOT_AUX>), dim3(nwg), dim3(256), 0, st, A, p, nullptr, r_hat, v, partials);
                 HIPCHK(hipGetLastError());
                 HIPCHK(launch_finalize_scalar(partials, nwg, red, S, STEP_SIGMA, st));
-                HIPCHK(launch_s_update(S, r, v, s, n, partials, st));
+                HIPCHK(launch_s_update(plain_scalars(S), r, v, s, n, partials, st));
                 HIPCHK(launch_finalize_scalar(partials, nwg_vec, red, S, STEP_SS, st));
                 hipLaunchKernelGGL((k_csr_apply<false, DOT_IN>), dim3(nwg), dim3(256), 0, st, A, s, nullptr, nullptr, t, partials);
                 HIPCHK(hipGetLastError());
                 HIPCHK(launch_finalize_scalar(partials, nwg, red, S, STEP_TSTT, st));
-                HIPCHK(launch_xr_update(S, u, p, s, s, t, r, r_hat, n, partials, st));
+                HIPCHK(launch_xr_update(plain_scalars(S), u, p, s, s, t, r, r_hat, n, partials, st));
                 HIPCHK(launch_finalize_scalar(partials, nwg_vec, red, S, STEP_RHO, st));
                 it_total += 1;
                 if (it_total % opt.check_every == 0 || it_total == opt.max_inner) {

@@ -125,6 +125,9 @@ constexpr int EDGE_BLOCK = 128;
 // out/in/xk/pq/aux are the rank-local vectors (owned rows then ghost rows)
 hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const double2* xk, const double2* pq, const double2* aux,
                             double2* out, double omega, int mode, int dot, double* partials, hipStream_t stream);
+// interior rows of n <= APPLY_BATCH_MAX blocks + the perimeter rows in one launch (Krylov modes); hipErrorNotSupported = no such kernel
+hipError_t launch_apply_edge_blocks(const ApplyBlock* blocks, int n, int mode, int dot, const EdgeRowsDev& e, const double2* in, const double2* xk,
+                                    const double2* pq, const double2* aux, double2* out, double* edge_partials, hipStream_t stream);
 // b (unscaled) per perimeter row scattered into a dense vector that was zeroed by the caller; scaled!=0 writes D^-1 b
 hipError_t launch_edge_rhs(const EdgeRowsDev& e, const double2* xk, const double2* pq, double2* rhs_out, int scaled,
                            double* partials /* [nwg*MAX_PARTIALS]: sum (D^-1 b)^2 x,y */, hipStream_t stream);
@@ -157,14 +160,35 @@ enum ScalarStep : int { STEP_INIT = 0, STEP_SIGMA = 1, STEP_SS = 2, STEP_TSTT = 
 hipError_t launch_scalar_update(KrylovScalars* S, const double* red, int step, hipStream_t stream, double rtol = 0.0, double atol = 0.0);
 hipError_t launch_finalize_scalar(const double* partials, int nwg, double* red, KrylovScalars* S, int step, hipStream_t stream, double rtol = 0.0,
                                   double atol = 0.0);
+// Scalar steps without launches of their own (small meshes are bound by dependent launches, ~5 us each, and a BiCGStab iteration
+// has four reductions): the kernel that CONSUMES the scalars applies the pending steps itself -- every workgroup sums the (few)
+// partial rows in the same fixed order and runs the step on a private copy of the scalars; workgroup 0 publishes the copy to
+// `S_out`, a different buffer than the `S_in` the other workgroups are still reading.  No device-wide fence is involved: kernel
+// boundaries order everything.  nsteps = 0: plain read of S_in.
+struct LazyStep {
+    int step;                  // ScalarStep
+    const double* partials;    // [nwg][MAX_PARTIALS]
+    int nwg;
+};
+struct LazyScalars {
+    const KrylovScalars* S_in = nullptr;
+    KrylovScalars* S_out = nullptr;
+    int nsteps = 0;
+    LazyStep st[2] = {{0, nullptr, 0}, {0, nullptr, 0}};
+};
+inline LazyScalars plain_scalars(const KrylovScalars* S) {
+    LazyScalars L;
+    L.S_in = S;
+    return L;
+}
 // p = r + beta (p - omega v)
-hipError_t launch_p_update(const KrylovScalars* S, const double2* r, double2* p, const double2* v, int64_t n, hipStream_t stream);
+hipError_t launch_p_update(const LazyScalars& S, const double2* r, double2* p, const double2* v, int64_t n, hipStream_t stream);
 // s = r - alpha v ; partials: ||s||^2 (x,y)
-hipError_t launch_s_update(const KrylovScalars* S, const double2* r, const double2* v, double2* s, int64_t n, double* partials,
+hipError_t launch_s_update(const LazyScalars& S, const double2* r, const double2* v, double2* s, int64_t n, double* partials,
                            hipStream_t stream);
 // u += alpha p + omega s ; r = s - omega t ; partials: r_hat.r (x,y), r.r (x,y)
 // u += alpha*p_hat + omega*s_hat; r = s - omega*t (p_hat = p, s_hat = s without a preconditioner)
-hipError_t launch_xr_update(const KrylovScalars* S, double2* u, const double2* p_hat, const double2* s_hat, const double2* s, const double2* t, double2* r,
+hipError_t launch_xr_update(const LazyScalars& S, double2* u, const double2* p_hat, const double2* s_hat, const double2* s, const double2* t, double2* r,
                             const double2* r_hat, int64_t n, double* partials, hipStream_t stream);
 // K7: partials sum (xk-u)^2 (x,y); xk <- u
 hipError_t launch_residual_copyback(double2* xk, const double2* u, int64_t n, double* partials, hipStream_t stream);

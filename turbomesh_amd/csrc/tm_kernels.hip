@@ -898,16 +898,16 @@ __device__ __forceinline__ double pick9(const double (&c)[9], int s) {
     return v;
 }
 
+// Workgroup `wg` of a perimeter-row pass; `tid` = thread within it (threads >= EDGE_BLOCK of a wider block idle).  Leaves the
+// thread's contributions to the fused dot products in acc[].
 template <int MODE, int DOT>
-__global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const double2* __restrict__ in,
-                                                          const double2* __restrict__ xk, const double2* __restrict__ pq,
-                                                          const double2* __restrict__ aux, double2* __restrict__ out, double omega,
-                                                          double* partials) {
+__device__ __forceinline__ void edge_rows_wg(const EdgeRowsDev& e, int wg, int tid, const double2* __restrict__ in, const double2* __restrict__ xk,
+                                             const double2* __restrict__ pq, const double2* __restrict__ aux, double2* __restrict__ out, double omega,
+                                             double (&acc)[MAX_PARTIALS]) {
     // one workgroup = one stretch of one run: everything read through R is workgroup-uniform (scalar loads)
-    const EdgeRun& R = e.runs[__builtin_amdgcn_readfirstlane(e.wg_run[blockIdx.x])];
-    const int k = __builtin_amdgcn_readfirstlane(e.wg_k0[blockIdx.x]) + static_cast<int>(threadIdx.x);
-    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
-    if (k < R.count) {
+    const EdgeRun& R = e.runs[__builtin_amdgcn_readfirstlane(e.wg_run[wg])];
+    const int k = __builtin_amdgcn_readfirstlane(e.wg_k0[wg]) + tid;
+    if (tid < EDGE_BLOCK && k < R.count) {
         const int row = R.row0 + k * R.row_stride;
         const int kind = R.kind;
         const int nc = R.ncols;
@@ -988,8 +988,40 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const d
             accumulate<DOT>(acc, w_self, o, (DOT == DOT_AUX || DOT == DOT_AUX2) ? aux[row] : ((DOT == DOT_DELTA) ? make_double2(o.x - w_self.x, o.y - w_self.y) : o));
         }
     }
+}
+
+template <int MODE, int DOT>
+__global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const double2* __restrict__ in,
+                                                          const double2* __restrict__ xk, const double2* __restrict__ pq,
+                                                          const double2* __restrict__ aux, double2* __restrict__ out, double omega,
+                                                          double* partials) {
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    edge_rows_wg<MODE, DOT>(e, blockIdx.x, threadIdx.x, in, xk, pq, aux, out, omega, acc);
     if (DOT != DOT_NONE) block_partials<EDGE_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
+
+// Interior rows of up to APPLY_BATCH_MAX blocks AND the perimeter rows of the rank in ONE launch (single-process handles: the
+// perimeter rows read nothing the interior pass writes, and nothing has to arrive from another rank in between).  Small meshes --
+// the reference's own inputs: 8 blocks, 25-38 k nodes -- are bound by dependent kernel launches (~5 us each), and the two passes
+// are each a handful of memory latencies long: side by side they cost one launch and one of those chains instead of two.
+template <int MODE, int DOT, bool HAS_PQ>
+__global__ __launch_bounds__(256) void k_apply_edge_batch(ApplyBatch B, int total_interior, EdgeRowsDev e, const double2* __restrict__ in,
+                                                          const double2* __restrict__ xk, const double2* __restrict__ pq,
+                                                          const double2* __restrict__ aux, double2* __restrict__ out, double* edge_partials) {
+    if (static_cast<int>(blockIdx.x) < total_interior) {   // workgroup-uniform
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < APPLY_BATCH_MAX; ++q)
+            if (q < B.n && static_cast<int>(blockIdx.x) >= B.start[q]) k = q;
+        apply_tile<MODE, DOT, false, HAS_PQ, 3, true>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], static_cast<int>(blockIdx.x) - B.start[k]);
+        return;
+    }
+    const int wg = static_cast<int>(blockIdx.x) - total_interior;
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    edge_rows_wg<MODE, DOT>(e, wg, threadIdx.x, in, xk, pq, aux, out, 0.0, acc);
+    if (DOT != DOT_NONE) block_partials<256>(acc, edge_partials + static_cast<size_t>(wg) * MAX_PARTIALS);   // waves 2, 3 add exact zeros
+}
+
 
 hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const double2* xk, const double2* pq, const double2* aux,
                             double2* out, double omega, int mode, int dot, double* partials, hipStream_t st) {
@@ -1012,6 +1044,43 @@ hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const doubl
 #undef TM_EDGE
     return hipErrorInvalidValue;
 }
+
+// One launch for the interior rows of `n` <= APPLY_BATCH_MAX blocks (Krylov flavour: the operator acts on a vector other than the
+// frozen field) and the perimeter rows `e`; hipErrorNotSupported when the combination has no merged kernel (caller falls back).
+hipError_t launch_apply_edge_blocks(const ApplyBlock* blocks, int n, int mode, int dot, const EdgeRowsDev& e, const double2* in, const double2* xk,
+                                    const double2* pq, const double2* aux, double2* out, double* edge_partials, hipStream_t st) {
+    if (n > APPLY_BATCH_MAX || e.nrows == 0) return hipErrorNotSupported;
+    ApplyBatch B;
+    B.n = 0;
+    int total = 0;
+    for (int k = 0; k < n; ++k) {
+        const ApplyBlock& a = blocks[k];
+        if (a.in == a.xk) return hipErrorNotSupported;   // field mode has its own kernels
+        if (a.ni < 3 || a.nj < 3) continue;
+        const int q = B.n++;
+        B.b[q] = a;
+        B.RI[q] = rows_per_chunk(a.ni);
+        B.nSG[q] = (a.nj + 255) / 256;
+        B.nRC[q] = (a.ni - 2 + B.RI[q] - 1) / B.RI[q];
+        B.start[q] = total;
+        total += B.nSG[q] * B.nRC[q];
+    }
+    for (int q = B.n; q < APPLY_BATCH_MAX; ++q) B.start[q] = total;
+    const dim3 grid(total + e.nwg), block(256);
+    const bool has_pq = pq != nullptr;
+#define TM_AE(M, D)                                                                                                                       \
+    if (mode == M && dot == D) {                                                                                                          \
+        if (has_pq) hipLaunchKernelGGL((k_apply_edge_batch<M, D, true>), grid, block, 0, st, B, total, e, in, xk, pq, aux, out, edge_partials);   \
+        else hipLaunchKernelGGL((k_apply_edge_batch<M, D, false>), grid, block, 0, st, B, total, e, in, xk, pq, aux, out, edge_partials);         \
+        return hipGetLastError();                                                                                                         \
+    }
+    TM_AE(MODE_SCALED, DOT_AUX)
+    TM_AE(MODE_SCALED, DOT_IN)
+    TM_AE(MODE_RESID, DOT_OUT2)
+#undef TM_AE
+    return hipErrorNotSupported;
+}
+
 
 // ------------------------------------------------------------------------------------------
 // Multigrid transfer kernels (N4): one thread per node of the level written, j fastest.  All HBM-bound and small next to
@@ -1378,6 +1447,38 @@ hipError_t launch_scalar_update(KrylovScalars* S, const double* red, int step, h
     return hipGetLastError();
 }
 
+// LazyScalars (tm_kernels.h): the scalars a vector kernel works with -- S_in as it stands, or S_in advanced by the pending steps.
+template <int NT>
+__device__ __forceinline__ const KrylovScalars* lazy_scalars(const LazyScalars& L) {
+    if (L.nsteps == 0) return L.S_in;   // uniform
+    __shared__ KrylovScalars shS;
+    __shared__ double shR[NT][MAX_PARTIALS];
+    constexpr int NWORDS = sizeof(KrylovScalars) / 4;
+    static_assert(sizeof(KrylovScalars) % 4 == 0 && NWORDS <= NT, "scalar block is copied one word per thread");
+    if (threadIdx.x < NWORDS) reinterpret_cast<uint32_t*>(&shS)[threadIdx.x] = reinterpret_cast<const uint32_t*>(L.S_in)[threadIdx.x];
+    for (int q = 0; q < L.nsteps; ++q) {
+        double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+        for (int i = threadIdx.x; i < L.st[q].nwg; i += NT) {
+#pragma unroll
+            for (int k = 0; k < MAX_PARTIALS; ++k) acc[k] += L.st[q].partials[static_cast<size_t>(i) * MAX_PARTIALS + k];
+        }
+#pragma unroll
+        for (int k = 0; k < MAX_PARTIALS; ++k) shR[threadIdx.x][k] = acc[k];
+        __syncthreads();
+        for (int off = NT / 2; off > 0; off >>= 1) {   // the tree of k_finalize: the same sums in every workgroup
+            if (static_cast<int>(threadIdx.x) < off) {
+#pragma unroll
+                for (int k = 0; k < MAX_PARTIALS; ++k) shR[threadIdx.x][k] += shR[threadIdx.x + off][k];
+            }
+            __syncthreads();
+        }
+        if (threadIdx.x < 2) scalar_update_body(&shS, &shR[0][0], L.st[q].step, 0.0, 0.0, threadIdx.x);
+        __syncthreads();
+    }
+    if (blockIdx.x == 0 && threadIdx.x < NWORDS) reinterpret_cast<uint32_t*>(L.S_out)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&shS)[threadIdx.x];
+    return &shS;
+}
+
 // The vector kernels stream 3-7 arrays far larger than the caches (256 MiB each at 4096^2) and re-use nothing: every thread
 // takes VEC_UNROLL elements per trip with all their loads issued before the first use (more requests in flight per wave), loads
 // and stores are non-temporal.
@@ -1387,8 +1488,9 @@ __device__ __forceinline__ double2 load_nt(const double2* src) {
     return make_double2(v.x, v.y);
 }
 
-__global__ __launch_bounds__(VEC_BLOCK) void k_p_update(const KrylovScalars* __restrict__ S, const double2* __restrict__ r,
+__global__ __launch_bounds__(VEC_BLOCK) void k_p_update(LazyScalars L, const double2* __restrict__ r,
                                                         double2* __restrict__ p, const double2* __restrict__ v, int64_t n) {
+    const KrylovScalars* S = lazy_scalars<VEC_BLOCK>(L);
     const double bx = S->beta[0], by = S->beta[1], ox = S->omega[0], oy = S->omega[1];
     const int64_t stride = static_cast<int64_t>(gridDim.x) * VEC_BLOCK;
     for (int64_t i0 = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i0 < n; i0 += stride * VEC_UNROLL) {
@@ -1407,14 +1509,15 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_p_update(const KrylovScalars* __r
         }
     }
 }
-hipError_t launch_p_update(const KrylovScalars* S, const double2* r, double2* p, const double2* v, int64_t n, hipStream_t st) {
+hipError_t launch_p_update(const LazyScalars& S, const double2* r, double2* p, const double2* v, int64_t n, hipStream_t st) {
     hipLaunchKernelGGL(k_p_update, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, S, r, p, v, n);
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(VEC_BLOCK) void k_s_update(const KrylovScalars* __restrict__ S, const double2* __restrict__ r,
+__global__ __launch_bounds__(VEC_BLOCK) void k_s_update(LazyScalars L, const double2* __restrict__ r,
                                                         const double2* __restrict__ v, double2* __restrict__ s, int64_t n,
                                                         double* partials) {
+    const KrylovScalars* S = lazy_scalars<VEC_BLOCK>(L);
     const double ax = S->alpha[0], ay = S->alpha[1];
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
     const int64_t stride = static_cast<int64_t>(gridDim.x) * VEC_BLOCK;
@@ -1439,15 +1542,16 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_s_update(const KrylovScalars* __r
     }
     block_partials<VEC_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
-hipError_t launch_s_update(const KrylovScalars* S, const double2* r, const double2* v, double2* s, int64_t n, double* partials,
+hipError_t launch_s_update(const LazyScalars& S, const double2* r, const double2* v, double2* s, int64_t n, double* partials,
                            hipStream_t st) {
     hipLaunchKernelGGL(k_s_update, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, S, r, v, s, n, partials);
     return hipGetLastError();
 }
 
-__global__ __launch_bounds__(VEC_BLOCK) void k_xr_update(const KrylovScalars* __restrict__ S, double2* __restrict__ u, const double2* p_hat,
+__global__ __launch_bounds__(VEC_BLOCK) void k_xr_update(LazyScalars L, double2* __restrict__ u, const double2* p_hat,
                                                          const double2* s_hat, const double2* s, const double2* __restrict__ t, double2* r,
                                                          const double2* __restrict__ r_hat, int64_t n, double* partials) {
+    const KrylovScalars* S = lazy_scalars<VEC_BLOCK>(L);
     const double ax = S->alpha[0], ay = S->alpha[1], ox = S->omega[0], oy = S->omega[1];
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
     const bool plain = (s_hat == s);   // no preconditioner: one stream less
@@ -1485,7 +1589,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_xr_update(const KrylovScalars* __
     }
     block_partials<VEC_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
-hipError_t launch_xr_update(const KrylovScalars* S, double2* u, const double2* p_hat, const double2* s_hat, const double2* s, const double2* t, double2* r,
+hipError_t launch_xr_update(const LazyScalars& S, double2* u, const double2* p_hat, const double2* s_hat, const double2* s, const double2* t, double2* r,
                             const double2* r_hat, int64_t n, double* partials, hipStream_t st) {
     hipLaunchKernelGGL(k_xr_update, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, S, u, p_hat, s_hat, s, t, r, r_hat, n, partials);
     return hipGetLastError();

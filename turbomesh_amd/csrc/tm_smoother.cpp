@@ -416,9 +416,16 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         nwg_apply2 = off2 + edge_nf.nwg;
     }
     nwg_vec = vec_nwg(n_owned);
-    partials = arena.alloc_n<double>(static_cast<uint64_t>(std::max(std::max(nwg_apply, nwg_apply2), nwg_vec)) * MAX_PARTIALS);
+    const uint64_t npart = static_cast<uint64_t>(std::max(std::max(nwg_apply, nwg_apply2), nwg_vec)) * MAX_PARTIALS;
+    // Krylov modes on a small single-process mesh: the scalar steps travel with the kernels that consume their result (LazyScalars,
+    // tm_kernels.h) -- three partial-sum buffers in rotation, two scalar blocks
+    lazy = !has_hooks && opt.inner != TM_INNER_RELAX && std::max(nwg_apply, nwg_vec) <= 512 && !(opt.flags & TM_OPT_EAGER_SCALARS);
+    for (int k = 0; k < (lazy ? 3 : 1); ++k) part_buf[k] = arena.alloc_n<double>(npart);
+    partials = part_buf[0];
     red = arena.alloc_n<double>(MAX_PARTIALS);
-    S = arena.alloc_n<KrylovScalars>(1);
+    S_buf[0] = arena.alloc_n<KrylovScalars>(1);
+    S_buf[1] = lazy ? arena.alloc_n<KrylovScalars>(1) : S_buf[0];
+    S = S_buf[0];
     sync_flags = arena.alloc_n<uint32_t>(64);   // [0] border passes done, [1] interior passes done, [2] a wait timed out
 
     // ---- halo exchange
@@ -431,7 +438,8 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
 
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_S), sizeof(KrylovScalars), hipHostMallocDefault));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_red), sizeof(double) * MAX_PARTIALS, hipHostMallocDefault));
-    HIPCHK(hipMemsetAsync(S, 0, sizeof(KrylovScalars), stream));
+    HIPCHK(hipMemsetAsync(S_buf[0], 0, sizeof(KrylovScalars), stream));
+    if (S_buf[1] != S_buf[0]) HIPCHK(hipMemsetAsync(S_buf[1], 0, sizeof(KrylovScalars), stream));
     HIPCHK(hipMemsetAsync(sync_flags, 0, sizeof(uint32_t) * 64, stream));
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_flags), sizeof(uint32_t) * 4, hipHostMallocDefault));
     for (double2* q : {p_hat, s_hat, mg_w0, mg_w1})
@@ -551,7 +559,36 @@ void Smoother::reduce_update(int nwg, int step, double rtol, double atol) {
         HIPCHK(launch_scalar_update(S, red, step, stream, rtol, atol));
         return;
     }
+    if (lazy && step != STEP_TOL) {   // no launch: the step waits for the kernel that needs its result (scalars_for)
+        if (npending == 2) flush_pending();
+        pending[npending++] = LazyStep{step, partials, nwg};
+        part_rot = (part_rot + 1) % 3;
+        partials = part_buf[part_rot];   // the next producer writes elsewhere: this buffer is read by the consumer's workgroups
+        return;
+    }
+    flush_pending();
     HIPCHK(launch_finalize_scalar(partials, nwg, red, S, step, stream, rtol, atol));
+}
+
+// pending steps applied by their own launches (before the host reads the scalars, or a step that cannot wait)
+void Smoother::flush_pending() {
+    for (int q = 0; q < npending; ++q) HIPCHK(launch_finalize_scalar(pending[q].partials, pending[q].nwg, red, S, pending[q].step, stream));
+    npending = 0;
+}
+
+// the scalars for a kernel that reads them: with pending steps, the kernel applies them itself and publishes the result to the
+// other scalar block, which is the current one from then on
+LazyScalars Smoother::scalars_for() {
+    LazyScalars L;
+    L.S_in = S;
+    if (npending == 0) return L;
+    KrylovScalars* other = (S == S_buf[0]) ? S_buf[1] : S_buf[0];
+    L.S_out = other;
+    L.nsteps = npending;
+    for (int q = 0; q < npending; ++q) L.st[q] = pending[q];
+    npending = 0;
+    S = other;
+    return L;
 }
 
 // runs `launch`; with profiling on, bracketed by a hipEvent pair on the handle's stream
@@ -602,6 +639,21 @@ void Smoother::apply(const double2* in, double2* out, int mode, int dot, const d
         a.nj = static_cast<int>(topo.nj[b]);
         a.omega = omega;
         a.partials = partials + static_cast<size_t>(poff[k]) * MAX_PARTIALS;
+    }
+    // Small meshes on a single-process handle: interior rows of all blocks AND the perimeter rows in one launch (no exchange has to
+    // land in between) -- they are bound by dependent launches, and the two passes are each a few memory latencies long.
+    if (!has_hooks && nwg_apply <= 1024 && !profile) {
+        const hipError_t rc = launch_apply_edge_blocks(blocks.data(), static_cast<int>(blocks.size()), mode, dot, edge, in, xk, PQ, aux, out,
+                                                       partials + static_cast<size_t>(poff_edge) * MAX_PARTIALS, stream);
+        if (rc == hipSuccess) {
+            if (dot != DOT_NONE && dot != DOT_DELTA) {
+                if (step >= 0) reduce_update(nwg_apply, step);
+                else reduce(nwg_apply);
+            }
+            return;
+        }
+        if (rc != hipErrorNotSupported) HIPCHK(rc);
+        (void)hipGetLastError();
     }
     // all owned blocks in one launch (groups of APPLY_BATCH_MAX): small multi-block meshes are launch-bound
     profiled([&]() { HIPCHK(launch_apply_blocks(blocks.data(), static_cast<int>(blocks.size()), mode, dot, stream)); });
@@ -671,6 +723,7 @@ int Smoother::picard_bicgstab(tm_stats& st) {
         HIPCHK(hipMemsetAsync(p, 0, sizeof(double2) * n_local, stream));
         HIPCHK(hipMemsetAsync(v, 0, sizeof(double2) * n_local, stream));
         if (restarts == 0) {   // scaled nonlinear residual of this outer iteration
+            flush_pending();
             HIPCHK(hipMemcpyAsync(h_S, S, sizeof(KrylovScalars), hipMemcpyDeviceToHost, stream));
             sync();
             st.scaled_residual_rms = std::sqrt((h_S->rr0[0] + h_S->rr0[1]) / (2.0 * static_cast<double>(dof_global)));
@@ -682,14 +735,14 @@ int Smoother::picard_bicgstab(tm_stats& st) {
         }
         bool breakdown = false;
         while (it_total < opt.max_inner) {
-            HIPCHK(launch_p_update(S, r, p, v, n_owned, stream));
+            HIPCHK(launch_p_update(scalars_for(), r, p, v, n_owned, stream));
             if (use_mg) {   // right preconditioning (BiCGStab.zig:314-316, 340-342 with M = one V-cycle)
                 precondition(p, p_hat);
                 apply(p_hat, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0, STEP_SIGMA);
             } else {
                 apply(p, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0, STEP_SIGMA);
             }
-            HIPCHK(launch_s_update(S, r, v, s, n_owned, partials, stream));
+            HIPCHK(launch_s_update(scalars_for(), r, v, s, n_owned, partials, stream));
             reduce_update(nwg_vec, STEP_SS);
             if (use_mg) {
                 precondition(s, s_hat);
@@ -697,11 +750,12 @@ int Smoother::picard_bicgstab(tm_stats& st) {
             } else {
                 apply(s, t, MODE_SCALED, DOT_IN, nullptr, X, 0.0, STEP_TSTT);
             }
-            HIPCHK(launch_xr_update(S, U, use_mg ? p_hat : p, use_mg ? s_hat : s, s, t, r, r_hat, n_owned, partials, stream));
+            HIPCHK(launch_xr_update(scalars_for(), U, use_mg ? p_hat : p, use_mg ? s_hat : s, s, t, r, r_hat, n_owned, partials, stream));
             reduce_update(nwg_vec, STEP_RHO);
             st.operator_sweeps += 2;
             it_total += 1;
             if (it_total % opt.check_every == 0 || it_total == opt.max_inner) {
+                flush_pending();
                 HIPCHK(hipMemcpyAsync(h_S, S, sizeof(KrylovScalars), hipMemcpyDeviceToHost, stream));
                 sync();
                 if (h_S->done[0] && h_S->done[1]) {
@@ -715,6 +769,7 @@ int Smoother::picard_bicgstab(tm_stats& st) {
         restarts += 1;   // breakdown (rho or omega vanished): restart from the current iterate
     }
     st.inner_iterations += it_total;
+    flush_pending();
 
     // residual + copy-back (smooth.zig:112-153); X becomes the new frozen field
     HIPCHK(launch_residual_copyback(X, U, n_owned, partials, stream));

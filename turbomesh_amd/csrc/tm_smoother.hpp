@@ -142,6 +142,15 @@ struct Smoother {
     void apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega, int step = -1);
     void reduce(int nwg);   // partials -> red (+ all-reduce)
     void reduce_update(int nwg, int step, double rtol = 0.0, double atol = 0.0);   // reduce + Krylov scalar update
+    // lazy scalar steps (small single-process meshes): see LazyScalars in tm_kernels.h
+    bool lazy = false;
+    double* part_buf[3] = {nullptr, nullptr, nullptr};
+    int part_rot = 0;
+    KrylovScalars* S_buf[2] = {nullptr, nullptr};
+    LazyStep pending[2];
+    int npending = 0;
+    void flush_pending();
+    LazyScalars scalars_for();
     void white_launch(int update);
     void sync();
     void ensure_tmp();

@@ -48,6 +48,7 @@ class Option:
     check_every: int = 0       # 0 -> 8
     omega: float = 0.0         # 0 -> 1.0
     single_sweep: bool = False # relax: one kernel pass per sweep (default: two sweeps per pass where possible)
+    eager_scalars: bool = False  # Krylov modes: a scalar-update launch per reduction (default: folded into the consuming kernels on small meshes)
 
     @classmethod
     def hip(cls, **kw):
@@ -55,7 +56,7 @@ class Option:
 
     def c_struct(self):
         return _capi.tm_solver_opt(int(self.tag), int(self.inner), self.rtol, self.atol, self.max_inner, self.check_every,
-                                   1 if self.single_sweep else 0, self.omega)
+                                   (1 if self.single_sweep else 0) | (2 if self.eager_scalars else 0), self.omega)
 
 
 class Solver:
