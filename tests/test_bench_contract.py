@@ -78,12 +78,18 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 
 
 @pytest.mark.gpu
-def test_bench_gpus4_config4_rehearsal_on_one_gpu_is_bit_identical_to_one_handle():
+@pytest.mark.parametrize("pair_sync", ["counters", "events"])
+def test_bench_gpus4_config4_rehearsal_on_one_gpu_is_bit_identical_to_one_handle(pair_sync):
     # `python bench.py --gpus 4 --config 4` launches its own ranks; rehearsed on ONE GPU with the gloo transport (halo rows staged
     # through the host; RCCL refuses two ranks on one device): strong scaling of the 8-block strip, 2 blocks per rank, and after
     # 4+21 sweeps every rank's blocks equal the single-handle run of the whole strip bit for bit.  4 ranks + this process <= 6.
+    # Both forms of the cross-queue ordering inside a sweep pair: one-wave signal / wait kernels on device-memory counters (the
+    # default for one multi-rank handle per process) and hipEvent record / wait (TM_PAIR_SYNC=events).
     env = dict(os.environ, TM_BENCH_SAME_DEVICE="1", TM_BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
+    env.pop("TM_PAIR_SYNC", None)
+    if pair_sync == "events":
+        env["TM_PAIR_SYNC"] = "events"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--config", "4", "--size", "96", "--steps", "21", "--warmup", "4",
                         "--verify", "--transport", "torch", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]

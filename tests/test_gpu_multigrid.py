@@ -66,7 +66,7 @@ def test_mg_white_control_function():
         st = sm.iterate(4)
         sm.download()
     assert st["not_converged"] == 0
-    assert _rms(mesh_flat(mesh), om.flat()) <= 1e-9   # same bar as the diagonal solver's White test (device acos/atan2)
+    assert _rms(mesh_flat(mesh), om.flat()) <= 1e-10   # north_star's bar; (P,Q) pass through ocml's acos / atan2 (ulp-level)
 
 
 def test_mg_t106_o4h():
