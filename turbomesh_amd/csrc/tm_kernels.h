@@ -85,13 +85,16 @@ std::vector<int32_t> relax2_border_tiles(int ni, int nj, int rows_per_chunk, int
 // from `mid` or writes its first-interior ring ALONG A SIDE WHOSE PERIMETER ROWS ARE NOT ALL `fixed` (Relax2Block::dyn); INSIDE = the rest (INSIDE_A / INSIDE_B: its two halves), which read nothing but
 // interior rows of X^k -- a multi-rank handle runs them while the halo exchanges are in flight.
 enum Relax2Subset { R2_ALL = 0, R2_BORDER = 1, R2_INSIDE_A = 2, R2_INSIDE_B = 3, R2_INSIDE = 4 };
-hipError_t launch_relax2_block(const Relax2Block& a, int rows_per_chunk, int dot, int subset, hipStream_t stream);
+// lds_bytes: dynamic LDS the launch asks for.  K2x2 needs none; a multi-rank interior pass asks for a third of the CU's 160 KB to cap
+// itself at 3 workgroups per CU (see Smoother::inside_lds).
+hipError_t launch_relax2_block(const Relax2Block& a, int rows_per_chunk, int dot, int subset, hipStream_t stream, size_t lds_bytes = 0);
 struct Relax2Batch {
     Relax2Block b[8];
     int RI[8], nSG[8], nRC[8], start[8];
     int n;
 };
-hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, int subset, hipStream_t stream);
+hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, int subset, hipStream_t stream,
+                                size_t lds_bytes = 0);
 void tune_fuse_rows(int rows);
 
 // ---- K4/K5 perimeter rows.  The rows of an interface are REGULAR: along a connection the row id, every column id and the

@@ -26,6 +26,7 @@
 // (row-chunk, strip) tiles: the halo lines shared by neighbouring tiles hit in that L2.
 #include "tm_kernels.h"
 #include "tm_devutil.hpp"
+#include <cstdlib>
 #include <type_traits>
 
 namespace tmh {
@@ -707,23 +708,23 @@ std::vector<int32_t> relax2_border_tiles(int ni, int nj, int RI, int dyn) {
     }
     return ids;
 }
-hipError_t launch_relax2_block(const Relax2Block& a, int RI, int dot, int subset, hipStream_t st) {
+hipError_t launch_relax2_block(const Relax2Block& a, int RI, int dot, int subset, hipStream_t st, size_t lds) {
     const int nstrips = (a.nj - 1 + 59) / 60;
     const int nSG = (nstrips + 3) / 4, nRC = relax2_nchunks(a.ni, RI);
     if (subset == R2_BORDER && a.nborder == 0) return hipSuccess;
     const dim3 grid(subset == R2_BORDER ? a.nborder : nSG * nRC), block(256);
     const bool w1 = a.omega == 1.0;
     if (dot == DOT_DELTA) {
-        if (w1) hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, true>), grid, block, 0, st, a, RI, nSG, nRC, subset);
-        else hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, false>), grid, block, 0, st, a, RI, nSG, nRC, subset);
+        if (w1) hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, true>), grid, block, lds, st, a, RI, nSG, nRC, subset);
+        else hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, false>), grid, block, lds, st, a, RI, nSG, nRC, subset);
     } else {
-        if (w1) hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, true, true>), grid, block, 0, st, a, RI, nSG, nRC, subset);
-        else hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, true, false>), grid, block, 0, st, a, RI, nSG, nRC, subset);
+        if (w1) hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, true, true>), grid, block, lds, st, a, RI, nSG, nRC, subset);
+        else hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, true, false>), grid, block, lds, st, a, RI, nSG, nRC, subset);
     }
     return hipGetLastError();
 }
-hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, int subset, hipStream_t st) {
-    if (n == 1) return launch_relax2_block(blocks[0], rows_per_chunk[0], dot, subset, st);
+hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, int subset, hipStream_t st, size_t lds) {
+    if (n == 1) return launch_relax2_block(blocks[0], rows_per_chunk[0], dot, subset, st, lds);
     for (int first = 0; first < n; first += APPLY_BATCH_MAX) {
         Relax2Batch B;
         B.n = 0;
@@ -743,11 +744,11 @@ hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_c
         if (total == 0) continue;
         const dim3 grid(total), block(256);
         if (dot == DOT_DELTA) {
-            if (w1) hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, true, true>), grid, block, 0, st, B, subset);
-            else hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, true, false>), grid, block, 0, st, B, subset);
+            if (w1) hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, true, true>), grid, block, lds, st, B, subset);
+            else hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, true, false>), grid, block, lds, st, B, subset);
         } else {
-            if (w1) hipLaunchKernelGGL((k_relax2_batch<DOT_NONE, R2_U, true, true>), grid, block, 0, st, B, subset);
-            else hipLaunchKernelGGL((k_relax2_batch<DOT_NONE, R2_U, true, false>), grid, block, 0, st, B, subset);
+            if (w1) hipLaunchKernelGGL((k_relax2_batch<DOT_NONE, R2_U, true, true>), grid, block, lds, st, B, subset);
+            else hipLaunchKernelGGL((k_relax2_batch<DOT_NONE, R2_U, true, false>), grid, block, lds, st, B, subset);
         }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;

@@ -227,6 +227,13 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     for (int64_t b = 0; b < topo.nblocks(); ++b)
         if (has_hooks || owner[b] == lp.rank) fuse_pairs = fuse_pairs && relax2_supported(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
     if (fuse_pairs) M = vec();
+    // Interior pass of a multi-rank sweep pair: when the chain through the border (perimeter rows -> border workgroups -> perimeter
+    // rows -> exchange) is longer than the interior pass -- blocks of a few million nodes -- its short kernels must not queue for
+    // wave slots: at the START of an interior pass every slot is taken and none is given back for ~10 us.  Asking for a third of
+    // the CU's 160 KB of LDS caps the interior pass at 3 workgroups per CU (its registers allow 4): 19.9 -> 18.2 us per sweep at
+    // 2048^2; at 4096^2 the interior pass is the longer one and the cap costs 3 % (58.4 -> 60.3), so it is not applied there.
+    if (fuse_pairs && has_hooks && lp.n_owned <= 6 * 1024 * 1024) inside_lds = 54 * 1024;
+    if (const char* e = std::getenv("TM_INSIDE_LDS_KB")) inside_lds = static_cast<size_t>(std::max(0, std::atoi(e))) * 1024;
 
     // ---- perimeter rows -> device SoA with rank-local ids
     const size_t nr = lp.rows.size();
@@ -807,7 +814,8 @@ void Smoother::relax2_launch(int subset, bool counts, int dot, hipStream_t on) {
         a.nborder = border_n[k];
         a.partials = partials + static_cast<size_t>(poff2[k]) * MAX_PARTIALS;
     }
-    profiled([&]() { HIPCHK(launch_relax2_blocks(blocks.data(), rows2.data(), static_cast<int>(blocks.size()), dot, subset, on)); }, counts, on);
+    const size_t lds = (subset == R2_INSIDE) ? inside_lds : 0;
+    profiled([&]() { HIPCHK(launch_relax2_blocks(blocks.data(), rows2.data(), static_cast<int>(blocks.size()), dot, subset, on, lds)); }, counts, on);
 }
 
 // want_partials: only the pass whose displacement norms are read back pays for them (the last one of an iterate() call)

@@ -69,6 +69,7 @@ struct Smoother {
     void precondition(const double2* in, double2* out);
     double2* M = nullptr;           // X^(k+1) of a fused pair of relax sweeps (perimeter + first-interior ring only)
     bool fuse_pairs = false;
+    size_t inside_lds = 0;          // dynamic LDS of the interior pass of a multi-rank sweep pair (occupancy cap, see create())
     // perimeter rows
     EdgeRowsDev edge;
     std::vector<double> h_rhs;   // host copy of the static rhs (refilled on upload), lp.rows order
