@@ -12,6 +12,7 @@
 #include <atomic>
 #include <chrono>
 #include <cmath>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 
@@ -352,6 +353,11 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
                 wg_run.push_back(static_cast<int32_t>(r));
                 wg_k0.push_back(k0);
             }
+        if (std::getenv("TM_DEBUG_RUNS")) {
+            int singles = 0;
+            for (const EdgeRun& R : runs) singles += R.count == 1;
+            std::fprintf(stderr, "[tm] perimeter-row table: %zu rows -> %zu runs (%d of one row), %zu workgroups\n", n, runs.size(), singles, wg_run.size());
+        }
         e.nrows = static_cast<int>(n);
         e.nwg = static_cast<int>(wg_run.size());
         e.runs = static_cast<const EdgeRun*>(up(runs.data(), runs.size() * sizeof(EdgeRun)));
