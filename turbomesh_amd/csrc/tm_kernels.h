@@ -136,7 +136,7 @@ hipError_t launch_edge_rhs(const EdgeRowsDev& e, const double2* xk, const double
                            double* partials /* [nwg*MAX_PARTIALS]: sum (D^-1 b)^2 x,y */, hipStream_t stream);
 
 // ---- ordering between two queues without barrier packets: one-wave kernels.  signal: *counter += 1 once everything before it in
-// its queue is complete and visible device-wide; wait: returns once *counter >= target (gives up after ~1 s and sets *error).
+// its queue is complete and visible device-wide; wait: returns once *counter >= target (gives up after tens of seconds and sets *error).
 hipError_t launch_queue_signal(uint32_t* counter, hipStream_t stream);
 hipError_t launch_queue_wait(const uint32_t* counter, uint32_t target, uint32_t* error, hipStream_t stream);
 hipError_t launch_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error, hipStream_t stream);

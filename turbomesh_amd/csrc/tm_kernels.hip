@@ -1279,24 +1279,27 @@ __global__ __launch_bounds__(64) void k_queue_signal(uint32_t* counter) {
 }
 __global__ __launch_bounds__(64) void k_queue_wait(const uint32_t* counter, uint32_t target, uint32_t* error) {
     if (threadIdx.x != 0) return;
+    // relaxed polls (an acquire per poll would invalidate this XCD's L2 every microsecond under the interior pass); the kernels
+    // behind this one start with the usual start-of-kernel acquire and see what the signalling queue had completed.  The limit is
+    // generous (tens of seconds): the first exchange of a new communicator sets up its connections and can take seconds, and
+    // everything queued behind it waits that long
     unsigned polls = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++polls > (1u << 22)) {   // ~1 s: fail the pass rather than hang the device
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++polls > (1u << 25)) {   // fail the pass rather than hang the device
             __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
     }
-    // the kernels behind this one start with the usual start-of-kernel acquire: they see what the signalling queue had completed
 }
 // both in one launch (a kernel boundary less on the handle's stream): announce what precedes, then wait for the other queue
 __global__ __launch_bounds__(64) void k_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error) {
     if (threadIdx.x != 0) return;
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
     unsigned polls = 0;
-    while (__hip_atomic_load(other, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(8);
-        if (++polls > (1u << 22)) {
+    while (__hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(16);
+        if (++polls > (1u << 25)) {
             __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }

@@ -866,8 +866,8 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
     // runs k_queue_signal behind the producing kernel (bumps a counter in device memory), the consumer queue runs k_queue_wait in
     // front of the consuming one (spins, with sleeps, until the counter has reached its target; kernel boundaries inside a queue
     // cost well under a microsecond).  A waiter's producer is always enqueued before it, in host order, so the pair cannot
-    // deadlock even if both streams share a hardware queue; a wait that is not met within ~1 s raises sync_flags[2] and the pass
-    // fails with TM_E_HIP instead of hanging the device.  Several multi-rank handles in ONE process (the virtual-rank tests) could
+    // deadlock even if both streams share a hardware queue; a wait that is not met within tens of seconds raises sync_flags[2] and
+    // the pass fails with TM_E_HIP instead of hanging the device.  Several multi-rank handles in ONE process (the virtual-rank tests) could
     // block each other through shared hardware queues: they use events.
     static const bool events_env = [] { const char* e = std::getenv("TM_PAIR_SYNC"); return e && std::strcmp(e, "events") == 0; }();
     const bool use_flags = !events_env && g_multirank_handles.load() <= 1;
