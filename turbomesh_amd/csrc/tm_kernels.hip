@@ -899,8 +899,97 @@ __device__ __forceinline__ double pick9(const double (&c)[9], int s) {
     return v;
 }
 
-// Workgroup `wg` of a perimeter-row pass; `tid` = thread within it (threads >= EDGE_BLOCK of a wider block idle).  Leaves the
+// Point k of run R.  fetch_in(q, id) / fetch_xk(m, id) deliver column q (metric neighbour m) whose local vector index is id,
+// fetch_self(id) the row's own value: plain loads in the perimeter-row kernel; the border workgroups of K2x2, which evaluate the
+// perimeter rows of their own columns in place (FoldRun), take the first-interior ring from registers instead.  Leaves the
 // thread's contributions to the fused dot products in acc[].
+template <int MODE, int DOT, class FIn, class FXk, class FSelf>
+__device__ __forceinline__ void edge_row_eval(const EdgeRun& R, const double* __restrict__ rhs, int k, FIn fetch_in, FXk fetch_xk, FSelf fetch_self,
+                                              const double2* __restrict__ pq, const double2* __restrict__ aux, double omega, double (&acc)[MAX_PARTIALS],
+                                              double2& result, int& row_out_id) {
+    const int row = R.row0 + k * R.row_stride;
+    row_out_id = row;
+    const int kind = R.kind;
+    const int nc = R.ncols;
+    const int self = R.self;
+    auto col = [&](int q) { return R.col0[q] + k * R.col_stride[q]; };
+    double sx = 0.0, sy = 0.0, rhs_x, rhs_y, diag_x, diag_y;
+    if (MODE == MODE_RELAX && kind == 5) {
+        // interior node of a REMOTE block, evaluated here as a ghost row (depth-2 halo): K2's own arithmetic on the gathered
+        // 3 x 3 neighbourhood (columns in (i-1,j-1) ... (i+1,j+1) order), bit-identical to what the owner's K2 / K2x2 stores
+        const double2 ml = fetch_in(0, col(0)), mc = fetch_in(1, col(1)), mr = fetch_in(2, col(2));
+        const double2 cl = fetch_in(3, col(3)), cc = fetch_in(4, col(4)), cr = fetch_in(5, col(5));
+        const double2 pl = fetch_in(6, col(6)), pc = fetch_in(7, col(7)), pr = fetch_in(8, col(8));
+        const double2 c_e = sub2(cr, cl);
+        double2 delta;
+        result = winslow_row<MODE_RELAX, false>(mc, sub2(mr, ml), cc, c_e, add2(cr, cl), pc, sub2(pr, pl), sub2(pc, mc), c_e, 0.0, 0.0, omega, delta);
+        return;
+    }
+    if (kind == 1 /* smoothed */) {
+        const double2 im1_j = fetch_xk(0, R.met0[0] + k * R.met_stride[0]), ip1_j = fetch_xk(1, R.met0[1] + k * R.met_stride[1]);
+        const double2 i_jm1 = fetch_xk(2, R.met0[2] + k * R.met_stride[2]);
+        double2 i_jp1 = fetch_xk(3, R.met0[3] + k * R.met_stride[3]);
+        const bool periodic = R.flags & 1;
+        const double per_x = R.per[0], per_y = R.per[1];
+        if (periodic) {   // types.add(p, types.neg(periodicity)), smooth.zig:1032
+            i_jp1.x = i_jp1.x + (-per_x);
+            i_jp1.y = i_jp1.y + (-per_y);
+        }
+        const double2 cf = pq ? pq[row] : make_double2(0.0, 0.0);
+        // periodic rows pass (P,Q), non-periodic rows pass (Q,P): smooth.zig:1040-1041 vs 1082-1083
+        const double P = periodic ? cf.x : cf.y, Q = periodic ? cf.y : cf.x;
+        double c[9];
+        stencil_coefs<true>(im1_j, ip1_j, i_jm1, i_jp1, P, Q, c);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const double ck = pick9(c, R.slot[q]);
+            const double2 w = fetch_in(q, col(q));
+            sx += ck * w.x;
+            sy += ck * w.y;
+        }
+        diag_x = diag_y = c[S_I_J];
+        if (periodic) {   // smooth.zig:1060-1061
+            const double cs = c[S_IM1_JP1] + c[S_I_JP1] + c[S_IP1_JP1];
+            rhs_x = per_x * cs;
+            rhs_y = per_y * cs;
+        } else {
+            rhs_x = 0.0;
+            rhs_y = 0.0;
+        }
+    } else {
+        diag_x = 0.0;
+        diag_y = 0.0;
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            if (q < nc) {
+                const double ax = R.cx[q], ay = R.cy[q];
+                const double2 w = fetch_in(q, col(q));
+                sx += ax * w.x;
+                sy += ay * w.y;
+                if (q == self) {
+                    diag_x = ax;
+                    diag_y = ay;
+                }
+            }
+        }
+        rhs_x = rhs[2 * (R.first + k)];
+        rhs_y = rhs[2 * (R.first + k) + 1];
+    }
+    const double2 w_self = fetch_self(row);
+    // ghost copies of rows whose right-hand side is the node's own boundary coordinate (fixed rows, the x-system of sliding
+    // rows): that coordinate IS the row's current value -- such a row reproduces it in every sweep
+    if (R.flags & 4) rhs_x = w_self.x;
+    if (R.flags & 8) rhs_y = w_self.y;
+    // constraint rows are enforced exactly in a relaxation sweep (omega = 1); smoothed rows relax like interior rows
+    const double om = (kind == 1) ? omega : 1.0;
+    double2 o;
+    o.x = row_out<MODE>(sx, rhs_x, diag_x, w_self.x, om);
+    o.y = row_out<MODE>(sy, rhs_y, diag_y, w_self.y, om);
+    result = o;
+    accumulate<DOT>(acc, w_self, o, (DOT == DOT_AUX || DOT == DOT_AUX2) ? aux[row] : ((DOT == DOT_DELTA) ? make_double2(o.x - w_self.x, o.y - w_self.y) : o));
+}
+
+// Workgroup `wg` of a perimeter-row pass; `tid` = thread within it (threads >= EDGE_BLOCK of a wider block idle).
 template <int MODE, int DOT>
 __device__ __forceinline__ void edge_rows_wg(const EdgeRowsDev& e, int wg, int tid, const double2* __restrict__ in, const double2* __restrict__ xk,
                                              const double2* __restrict__ pq, const double2* __restrict__ aux, double2* __restrict__ out, double omega,
@@ -909,85 +998,11 @@ __device__ __forceinline__ void edge_rows_wg(const EdgeRowsDev& e, int wg, int t
     const EdgeRun& R = e.runs[__builtin_amdgcn_readfirstlane(e.wg_run[wg])];
     const int k = __builtin_amdgcn_readfirstlane(e.wg_k0[wg]) + tid;
     if (tid < EDGE_BLOCK && k < R.count) {
-        const int row = R.row0 + k * R.row_stride;
-        const int kind = R.kind;
-        const int nc = R.ncols;
-        const int self = R.self;
-        auto col = [&](int q) { return R.col0[q] + k * R.col_stride[q]; };
-        double sx = 0.0, sy = 0.0, rhs_x, rhs_y, diag_x, diag_y;
-        if (MODE == MODE_RELAX && kind == 5) {
-            // interior node of a REMOTE block, evaluated here as a ghost row (depth-2 halo): K2's own arithmetic on the gathered
-            // 3 x 3 neighbourhood (columns in (i-1,j-1) ... (i+1,j+1) order), bit-identical to what the owner's K2 / K2x2 stores
-            const double2 ml = in[col(0)], mc = in[col(1)], mr = in[col(2)];
-            const double2 cl = in[col(3)], cc = in[col(4)], cr = in[col(5)];
-            const double2 pl = in[col(6)], pc = in[col(7)], pr = in[col(8)];
-            const double2 c_e = sub2(cr, cl);
-            double2 delta;
-            out[row] = winslow_row<MODE_RELAX, false>(mc, sub2(mr, ml), cc, c_e, add2(cr, cl), pc, sub2(pr, pl), sub2(pc, mc), c_e, 0.0, 0.0, omega, delta);
-        } else {
-            if (kind == 1 /* smoothed */) {
-                const double2 im1_j = xk[R.met0[0] + k * R.met_stride[0]], ip1_j = xk[R.met0[1] + k * R.met_stride[1]];
-                const double2 i_jm1 = xk[R.met0[2] + k * R.met_stride[2]];
-                double2 i_jp1 = xk[R.met0[3] + k * R.met_stride[3]];
-                const bool periodic = R.flags & 1;
-                const double per_x = R.per[0], per_y = R.per[1];
-                if (periodic) {   // types.add(p, types.neg(periodicity)), smooth.zig:1032
-                    i_jp1.x = i_jp1.x + (-per_x);
-                    i_jp1.y = i_jp1.y + (-per_y);
-                }
-                const double2 cf = pq ? pq[row] : make_double2(0.0, 0.0);
-                // periodic rows pass (P,Q), non-periodic rows pass (Q,P): smooth.zig:1040-1041 vs 1082-1083
-                const double P = periodic ? cf.x : cf.y, Q = periodic ? cf.y : cf.x;
-                double c[9];
-                stencil_coefs<true>(im1_j, ip1_j, i_jm1, i_jp1, P, Q, c);
-#pragma unroll
-                for (int q = 0; q < 9; ++q) {
-                    const double ck = pick9(c, R.slot[q]);
-                    const double2 w = in[col(q)];
-                    sx += ck * w.x;
-                    sy += ck * w.y;
-                }
-                diag_x = diag_y = c[S_I_J];
-                if (periodic) {   // smooth.zig:1060-1061
-                    const double cs = c[S_IM1_JP1] + c[S_I_JP1] + c[S_IP1_JP1];
-                    rhs_x = per_x * cs;
-                    rhs_y = per_y * cs;
-                } else {
-                    rhs_x = 0.0;
-                    rhs_y = 0.0;
-                }
-            } else {
-                diag_x = 0.0;
-                diag_y = 0.0;
-#pragma unroll
-                for (int q = 0; q < 9; ++q) {
-                    if (q < nc) {
-                        const double ax = R.cx[q], ay = R.cy[q];
-                        const double2 w = in[col(q)];
-                        sx += ax * w.x;
-                        sy += ay * w.y;
-                        if (q == self) {
-                            diag_x = ax;
-                            diag_y = ay;
-                        }
-                    }
-                }
-                rhs_x = e.rhs[2 * (R.first + k)];
-                rhs_y = e.rhs[2 * (R.first + k) + 1];
-            }
-            const double2 w_self = in[row];
-            // ghost copies of rows whose right-hand side is the node's own boundary coordinate (fixed rows, the x-system of sliding
-            // rows): that coordinate IS the row's current value -- such a row reproduces it in every sweep
-            if (R.flags & 4) rhs_x = w_self.x;
-            if (R.flags & 8) rhs_y = w_self.y;
-            // constraint rows are enforced exactly in a relaxation sweep (omega = 1); smoothed rows relax like interior rows
-            const double om = (kind == 1) ? omega : 1.0;
-            double2 o;
-            o.x = row_out<MODE>(sx, rhs_x, diag_x, w_self.x, om);
-            o.y = row_out<MODE>(sy, rhs_y, diag_y, w_self.y, om);
-            out[row] = o;
-            accumulate<DOT>(acc, w_self, o, (DOT == DOT_AUX || DOT == DOT_AUX2) ? aux[row] : ((DOT == DOT_DELTA) ? make_double2(o.x - w_self.x, o.y - w_self.y) : o));
-        }
+        double2 o;
+        int row;
+        edge_row_eval<MODE, DOT>(R, e.rhs, k, [&](int, int id) { return in[id]; }, [&](int, int id) { return xk[id]; }, [&](int id) { return in[id]; }, pq, aux,
+                                 omega, acc, o, row);
+        out[row] = o;
     }
 }
 
