@@ -911,8 +911,10 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
     if (!use_flags || npairs == 1) signal_inside();   // with counters the announcement travels with the next wait (one launch)
     relax2_launch(R2_BORDER, true, dot, side);
     for (uint64_t k = 0; k < npairs; ++k) {
-        if (k + 1 < npairs) signal_border();          // the border workgroups of pair k are done
         edge_on_side(edge_nf, M, U, dot);             // E2(k): perimeter rows of the pair's output (ghost operands: M's ghost rows)
+        // "the border workgroups of pair k are done" -- announced BEHIND E2: the interior pass k+1 that waits for it cannot start before
+        // interior pass k has ended anyway, long after this point, and the chain is one launch shorter in front of the exchange
+        if (k + 1 < npairs) signal_border();
         std::swap(X, U);
         if (k + 1 == npairs) {
             fence(side, stream, ev_to_main);          // the main stream continues behind the whole chain
