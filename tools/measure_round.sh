@@ -1,0 +1,33 @@
+#!/bin/bash
+# The probes behind the numbers DESIGN.md / README.md quote, in one run on the MI355X box (through gpurun, from the repo root):
+#   tools/measure_round.sh r02   ->  gpurun_out/<tag>_measurements.txt   (copy into profiles/)
+tag=${1:-r02}
+out=gpurun_out/${tag}_measurements.txt
+mkdir -p gpurun_out
+{
+  echo "# $tag measurements, $(date -u +%Y-%m-%dT%H:%MZ), $(python3 -c 'import torch; print(torch.cuda.get_device_name(0))' 2>/dev/null)"
+  echo "## K1 (tools/tfi_probe.py)"; python3 tools/tfi_probe.py 4096 2>/dev/null; python3 tools/tfi_probe.py 2048 2>/dev/null
+  echo "## single-rank relaxation sweeps (two per pass), us per sweep"
+  python3 - <<'PY' 2>/dev/null
+import sys
+sys.path.insert(0, ".")
+from turbomesh_amd import configs
+from turbomesh_amd.smoothing import smooth, solver
+for n in (1024, 2048, 4096):
+    m = configs.single_block(n, n)
+    with smooth.Smoother(m, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+        sm.iterate(20)
+        st = sm.iterate(400)
+    print(f"{n}^2 single block: {st['seconds'] / 400 * 1e6:.1f} us per sweep")
+PY
+  echo "## one rank of a strip, transport that moves nothing (tools/split_path_cost.py), signal / wait kernels"
+  for n in 4096 2048 1024; do python3 tools/split_path_cost.py $n 2>/dev/null | grep Native; done
+  echo "## the same with hipEvent record / wait (TM_PAIR_SYNC=events)"
+  for n in 4096 2048; do TM_PAIR_SYNC=events python3 tools/split_path_cost.py $n 2>/dev/null | grep Native; done
+  echo "## BASELINE configs[3] / [4] on one GPU"; python3 tools/config4_probe.py 2>/dev/null | tail -2; python3 tools/config5_probe.py 2>/dev/null | tail -2
+  echo "## the reference's example inputs as written, 10 Picard iterations, hip solver (tools/t106_probe.py)"
+  python3 tools/t106_probe.py T106 2>/dev/null | tail -1; python3 tools/t106_probe.py LS89 2>/dev/null | tail -1
+  echo "## perturbed 4096^2 block to a scaled residual <= 1e-8 (tools/solve_probe.py)"; python3 tools/solve_probe.py 4096 1e-6 1e-10 2>/dev/null
+  echo "## host-buffer seam, PCIe inclusive (tools/oneshot_probe.py)"; python3 tools/oneshot_probe.py 2>/dev/null | tail -4
+} > "$out" 2>&1
+cat "$out"
