@@ -32,11 +32,15 @@ enum DotMode : int {
     DOT_IN = 2,     // [in.out]_x, [in.out]_y, [out.out]_x, [out.out]_y   (t.s, t.t)
     DOT_OUT2 = 3,   // [out.out]_x, [out.out]_y                       (||r||^2)
     DOT_DELTA = 4,  // [(out-in)^2]_x, [(out-in)^2]_y                 (relax: sum dx^2, dy^2)
-    DOT_AUX2 = 5    // [aux.out]_x, [aux.out]_y, [out.out]_x, [out.out]_y (t.s, t.t when the operator acted on a preconditioned vector)
+    DOT_AUX2 = 5,   // [aux.out]_x, [aux.out]_y, [out.out]_x, [out.out]_y (t.s, t.t when the operator acted on a preconditioned vector)
+    DOT_IN_SS = 6   // DOT_IN + [in.in]_x, [in.in]_y   (t.s, t.t, ||s||^2: the second apply of an iteration acting on s = r - alpha v formed on the fly)
 };
-constexpr int MAX_PARTIALS = 4;
+constexpr int MAX_PARTIALS = 6;
+struct KrylovScalars;
+struct LazyScalars;
 
 struct ApplyBlock {
+    const double2* in2 = nullptr;   // VIN kernels: the operator acts on  in - alpha * in2  (s = r - alpha v, BiCGStab.zig:325-327) formed on the fly
     const double2* in;    // vector the operator acts on, pointing at the block's node (0,0)
     const double2* xk;    // frozen coordinates the coefficients are built from (== in for field mode)
     const double2* pq;    // control function (P,Q) or nullptr (Laplace)
@@ -131,6 +135,11 @@ hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const doubl
 // interior rows of n <= APPLY_BATCH_MAX blocks + the perimeter rows in one launch (Krylov modes); hipErrorNotSupported = no such kernel
 hipError_t launch_apply_edge_blocks(const ApplyBlock* blocks, int n, int mode, int dot, const EdgeRowsDev& e, const double2* in, const double2* xk,
                                     const double2* pq, const double2* aux, double2* out, double* edge_partials, hipStream_t stream);
+// Second apply of a BiCGStab iteration with the s-update folded in (single process): t = D^-1 A (r - alpha v), s never stored.
+// Interior rows of all blocks (one launch per group of APPLY_BATCH_MAX) and the perimeter rows; alpha from `scal` (pending steps
+// applied by the first kernel that runs).  Partial sums: DOT_IN_SS.
+hipError_t launch_apply_vin(const ApplyBlock* blocks, int n, const EdgeRowsDev& e, const double2* r, const double2* v, const double2* xk, const double2* pq,
+                            double2* out, double* edge_partials, const LazyScalars& scal, hipStream_t stream);
 // b (unscaled) per perimeter row scattered into a dense vector that was zeroed by the caller; scaled!=0 writes D^-1 b
 hipError_t launch_edge_rhs(const EdgeRowsDev& e, const double2* xk, const double2* pq, double2* rhs_out, int scaled,
                            double* partials /* [nwg*MAX_PARTIALS]: sum (D^-1 b)^2 x,y */, hipStream_t stream);
@@ -158,7 +167,8 @@ struct KrylovScalars {   // one per smoother, lives in device memory; index = co
 constexpr int VEC_BLOCK = 256;
 int vec_nwg(int64_t n);
 // step ids for launch_scalar_update: consume red[], update KrylovScalars
-enum ScalarStep : int { STEP_INIT = 0, STEP_SIGMA = 1, STEP_SS = 2, STEP_TSTT = 3, STEP_RHO = 4, STEP_TOL = 5 };
+enum ScalarStep : int { STEP_INIT = 0, STEP_SIGMA = 1, STEP_SS = 2, STEP_TSTT = 3, STEP_RHO = 4, STEP_TOL = 5, STEP_SS_TSTT = 6 };
+// STEP_SS_TSTT: red[4..5] = ||s||^2, red[0..1] = t.s, red[2..3] = t.t -- STEP_SS then STEP_TSTT from one reduction (DOT_IN_SS)
 // STEP_TOL: red[0..1] = ||D^-1 b||^2 -> tol2 = max(atol, rtol*||D^-1 b||)^2
 hipError_t launch_scalar_update(KrylovScalars* S, const double* red, int step, hipStream_t stream, double rtol = 0.0, double atol = 0.0);
 hipError_t launch_finalize_scalar(const double* partials, int nwg, double* red, KrylovScalars* S, int step, hipStream_t stream, double rtol = 0.0,
@@ -193,6 +203,9 @@ hipError_t launch_s_update(const LazyScalars& S, const double2* r, const double2
 // u += alpha*p_hat + omega*s_hat; r = s - omega*t (p_hat = p, s_hat = s without a preconditioner)
 hipError_t launch_xr_update(const LazyScalars& S, double2* u, const double2* p_hat, const double2* s_hat, const double2* s, const double2* t, double2* r,
                             const double2* r_hat, int64_t n, double* partials, hipStream_t stream);
+// the same with s = r - alpha v formed on the fly (s was never stored): reads p, r, v, t, r_hat, u; r is updated in place
+hipError_t launch_xr_update_vs(const LazyScalars& S, double2* u, const double2* p, const double2* v, const double2* t, double2* r, const double2* r_hat,
+                               int64_t n, double* partials, hipStream_t stream);
 // K7: partials sum (xk-u)^2 (x,y); xk <- u
 hipError_t launch_residual_copyback(double2* xk, const double2* u, int64_t n, double* partials, hipStream_t stream);
 // gather rows for the halo exchange: dst[k] = src[ids[k]]

@@ -127,6 +127,13 @@ __device__ __forceinline__ void accumulate(double (&acc)[MAX_PARTIALS], double2 
         acc[1] += in_self.y * out.y;
         acc[2] += out.x * out.x;
         acc[3] += out.y * out.y;
+    } else if (DOT == DOT_IN_SS) {
+        acc[0] += in_self.x * out.x;
+        acc[1] += in_self.y * out.y;
+        acc[2] += out.x * out.x;
+        acc[3] += out.y * out.y;
+        acc[4] += in_self.x * in_self.x;
+        acc[5] += in_self.y * in_self.y;
     } else if (DOT == DOT_OUT2) {
         acc[0] += out.x * out.x;
         acc[1] += out.y * out.y;
@@ -213,6 +220,9 @@ __device__ __forceinline__ double2 winslow_row(double2 m_c, double2 e_m, double2
 __device__ __forceinline__ double2 sub2(double2 a, double2 b) { return make_double2(a.x - b.x, a.y - b.y); }
 __device__ __forceinline__ double2 add2(double2 a, double2 b) { return make_double2(a.x + b.x, a.y + b.y); }
 
+template <int NT>
+__device__ __forceinline__ const KrylovScalars* lazy_scalars(const LazyScalars& L);   // defined with the Krylov vector kernels
+
 // ------------------------------------------------------------------------------------------
 // K2  winslow_apply: interior rows of one block (replaces smooth.zig:923-992 fill +
 //     BiCGStab.zig:424-435 mat-vec), matrix-free, factored row evaluation (winslow_row)
@@ -231,8 +241,9 @@ __device__ __forceinline__ void store_nt(double2* dst, double2 v) {
 }
 
 // One workgroup's tile of one block; `bid` = the workgroup's index within that block's tiles (also its partial-sum slot).
-template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool NT>
-__device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG, int nRC, int bid) {
+// VIN: the operator acts on the vector  in - alpha * in2  (component-wise alpha = va) formed as the rows are taken into the window
+template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool NT, bool VIN = false>
+__device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG, int nRC, int bid, double2 va = make_double2(0.0, 0.0)) {
     static_assert(U % 3 == 0, "the 3-row window rotates by renaming: the row group must be a multiple of 3");
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -267,10 +278,20 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
         // 3-row window of the vector, rotating by index: slot (r % 3) holds row i0-1+r as (value, e = right - left, h = right + left)
         double2 Wc[3], We[3], Wh[3];
         double2 Xc[3], Xdet = make_double2(0.0, 0.0);   // frozen coordinates when they are a different array; Xdet of the centre row
+        auto comb = [&](double2 x, double2 y) { return make_double2(x.x - va.x * y.x, x.y - va.y * y.y); };   // BiCGStab.zig:325-327, k_s_update's expression
         {
             double2 h0, h1;
             load_row(a.in, i0 - 1, Wc[0], h0);
             load_row(a.in, i0, Wc[1], h1);
+            if (VIN) {
+                double2 q0, g0, q1, g1;
+                load_row(a.in2, i0 - 1, q0, g0);
+                load_row(a.in2, i0, q1, g1);
+                Wc[0] = comb(Wc[0], q0);
+                h0 = comb(h0, g0);
+                Wc[1] = comb(Wc[1], q1);
+                h1 = comb(h1, g1);
+            }
             const double2 l0 = lane_prev(h0, Wc[0]), r0 = lane_next(h0, Wc[0]), l1 = lane_prev(h1, Wc[1]), r1 = lane_next(h1, Wc[1]);
             We[0] = sub2(r0, l0); Wh[0] = add2(r0, l0);
             We[1] = sub2(r1, l1); Wh[1] = add2(r1, l1);
@@ -285,7 +306,7 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
         }
 
         struct Group {
-            double2 pc[U], ph[U], xpc[U], xph[U], pqv[U], auxv[U];
+            double2 pc[U], ph[U], xpc[U], xph[U], pqv[U], auxv[U], qc[VIN ? U : 1], qh[VIN ? U : 1];
         };
         auto load_group = [&](int ib, Group& g) {   // rows ib+1 .. ib+U of the vector (and of xk), pq/aux of rows ib .. ib+U-1
 #pragma unroll
@@ -296,6 +317,7 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
                     g.ph[u] = Wh[1];
                 } else
                     load_row(a.in, prow, g.pc[u], g.ph[u]);
+                if (VIN) load_row(a.in2, prow, g.qc[u], g.qh[u]);
                 if (!FIELD) load_row(a.xk, prow, g.xpc[u], g.xph[u]);
                 const size_t cur = static_cast<size_t>(min(ib + u, ni - 2)) * nj + jc;
                 if (HAS_PQ) g.pqv[u] = a.pq[cur];
@@ -309,9 +331,10 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
             for (int u = 0; u < U; ++u) {
                 const int M = u % 3, C = (u + 1) % 3, P3 = (u + 2) % 3;   // window slots of rows i-1, i, i+1
                 const int row = ib + u;
-                Wc[P3] = g.pc[u];
+                const double2 nc = VIN ? comb(g.pc[u], g.qc[u]) : g.pc[u], nh = VIN ? comb(g.ph[u], g.qh[u]) : g.ph[u];
+                Wc[P3] = nc;
                 {
-                    const double2 l = lane_prev(g.ph[u], g.pc[u]), r = lane_next(g.ph[u], g.pc[u]);
+                    const double2 l = lane_prev(nh, nc), r = lane_next(nh, nc);
                     We[P3] = sub2(r, l);
                     Wh[P3] = add2(r, l);
                 }
@@ -990,17 +1013,24 @@ __device__ __forceinline__ void edge_row_eval(const EdgeRun& R, const double* __
 }
 
 // Workgroup `wg` of a perimeter-row pass; `tid` = thread within it (threads >= EDGE_BLOCK of a wider block idle).
-template <int MODE, int DOT>
+template <int MODE, int DOT, bool VIN = false>
 __device__ __forceinline__ void edge_rows_wg(const EdgeRowsDev& e, int wg, int tid, const double2* __restrict__ in, const double2* __restrict__ xk,
                                              const double2* __restrict__ pq, const double2* __restrict__ aux, double2* __restrict__ out, double omega,
-                                             double (&acc)[MAX_PARTIALS]) {
+                                             double (&acc)[MAX_PARTIALS], const double2* __restrict__ in2 = nullptr, double2 va = make_double2(0.0, 0.0)) {
     // one workgroup = one stretch of one run: everything read through R is workgroup-uniform (scalar loads)
     const EdgeRun& R = e.runs[__builtin_amdgcn_readfirstlane(e.wg_run[wg])];
     const int k = __builtin_amdgcn_readfirstlane(e.wg_k0[wg]) + tid;
     if (tid < EDGE_BLOCK && k < R.count) {
         double2 o;
         int row;
-        edge_row_eval<MODE, DOT>(R, e.rhs, k, [&](int, int id) { return in[id]; }, [&](int, int id) { return xk[id]; }, [&](int id) { return in[id]; }, pq, aux,
+        // VIN: the vector is  in - alpha * in2  formed on the fly (same expression as k_s_update)
+        auto vec = [&](int id) {
+            const double2 x = in[id];
+            if (!VIN) return x;
+            const double2 y = in2[id];
+            return make_double2(x.x - va.x * y.x, x.y - va.y * y.y);
+        };
+        edge_row_eval<MODE, DOT>(R, e.rhs, k, [&](int, int id) { return vec(id); }, [&](int, int id) { return xk[id]; }, [&](int id) { return vec(id); }, pq, aux,
                                  omega, acc, o, row);
         out[row] = o;
     }
@@ -1036,6 +1066,38 @@ __global__ __launch_bounds__(256) void k_apply_edge_batch(ApplyBatch B, int tota
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
     edge_rows_wg<MODE, DOT>(e, wg, threadIdx.x, in, xk, pq, aux, out, 0.0, acc);
     if (DOT != DOT_NONE) block_partials<256>(acc, edge_partials + static_cast<size_t>(wg) * MAX_PARTIALS);   // waves 2, 3 add exact zeros
+}
+
+// Second apply of a BiCGStab iteration with the s-update folded in: t = D^-1 A s, s = r - alpha v formed as the rows enter the
+// window (b.in = r, b.in2 = v), partial sums t.s, t.t and ||s||^2 (DOT_IN_SS); s itself is never stored -- k_xr_update_vs forms it
+// again.  alpha comes from the scalar block, advanced by the pending steps where there are any (LazyScalars).
+// total_interior < 0: interior rows only (the perimeter rows follow in k_edge_rows_vin: large meshes).
+template <bool HAS_PQ>
+__global__ __launch_bounds__(256) void k_apply_vin(ApplyBatch B, int total_interior, EdgeRowsDev e, const double2* __restrict__ r, const double2* __restrict__ v,
+                                                   const double2* __restrict__ xk, const double2* __restrict__ pq, double2* __restrict__ out,
+                                                   double* edge_partials, LazyScalars L) {
+    const KrylovScalars* S = lazy_scalars<256>(L);
+    const double2 va = make_double2(S->alpha[0], S->alpha[1]);
+    if (total_interior < 0 || static_cast<int>(blockIdx.x) < total_interior) {   // workgroup-uniform
+        int k = 0;
+#pragma unroll
+        for (int q = 1; q < APPLY_BATCH_MAX; ++q)
+            if (q < B.n && static_cast<int>(blockIdx.x) >= B.start[q]) k = q;
+        apply_tile<MODE_SCALED, DOT_IN_SS, false, HAS_PQ, 3, true, true>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], static_cast<int>(blockIdx.x) - B.start[k], va);
+        return;
+    }
+    const int wg = static_cast<int>(blockIdx.x) - total_interior;
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    edge_rows_wg<MODE_SCALED, DOT_IN_SS, true>(e, wg, threadIdx.x, r, xk, pq, nullptr, out, 0.0, acc, v, va);
+    block_partials<256>(acc, edge_partials + static_cast<size_t>(wg) * MAX_PARTIALS);
+}
+__global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows_vin(EdgeRowsDev e, const double2* __restrict__ r, const double2* __restrict__ v,
+                                                              const double2* __restrict__ xk, const double2* __restrict__ pq, double2* __restrict__ out,
+                                                              double* partials, const KrylovScalars* __restrict__ S) {
+    const double2 va = make_double2(S->alpha[0], S->alpha[1]);
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    edge_rows_wg<MODE_SCALED, DOT_IN_SS, true>(e, blockIdx.x, threadIdx.x, r, xk, pq, nullptr, out, 0.0, acc, v, va);
+    block_partials<EDGE_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
 
 
@@ -1095,6 +1157,48 @@ hipError_t launch_apply_edge_blocks(const ApplyBlock* blocks, int n, int mode, i
     TM_AE(MODE_RESID, DOT_OUT2)
 #undef TM_AE
     return hipErrorNotSupported;
+}
+
+hipError_t launch_apply_vin(const ApplyBlock* blocks, int n, const EdgeRowsDev& e, const double2* r, const double2* v, const double2* xk, const double2* pq,
+                            double2* out, double* edge_partials, const LazyScalars& scal, hipStream_t st) {
+    if (e.nrows == 0) return hipErrorInvalidValue;
+    const bool has_pq = pq != nullptr;
+    const bool merged = n <= APPLY_BATCH_MAX;   // one launch for everything; else interior groups first, perimeter rows last
+    LazyScalars L = scal;
+    for (int first = 0; first < n; first += APPLY_BATCH_MAX) {
+        ApplyBatch B;
+        B.n = 0;
+        int total = 0;
+        for (int k = first; k < n && B.n < APPLY_BATCH_MAX; ++k) {
+            const ApplyBlock& a = blocks[k];
+            if (a.ni < 3 || a.nj < 3) continue;
+            const int q = B.n++;
+            B.b[q] = a;
+            B.RI[q] = rows_per_chunk(a.ni);
+            B.nSG[q] = (a.nj + 255) / 256;
+            B.nRC[q] = (a.ni - 2 + B.RI[q] - 1) / B.RI[q];
+            B.start[q] = total;
+            total += B.nSG[q] * B.nRC[q];
+        }
+        for (int q = B.n; q < APPLY_BATCH_MAX; ++q) B.start[q] = total;
+        const dim3 grid(merged ? total + e.nwg : total), block(256);
+        if (grid.x == 0) continue;
+        const int ti = merged ? total : -1;
+        if (has_pq) hipLaunchKernelGGL((k_apply_vin<true>), grid, block, 0, st, B, ti, e, r, v, xk, pq, out, edge_partials, L);
+        else hipLaunchKernelGGL((k_apply_vin<false>), grid, block, 0, st, B, ti, e, r, v, xk, pq, out, edge_partials, L);
+        const hipError_t rc = hipGetLastError();
+        if (rc != hipSuccess) return rc;
+        if (L.nsteps) {   // the first launch has applied and published the pending steps: later ones read the published block
+            L.S_in = L.S_out;
+            L.S_out = nullptr;
+            L.nsteps = 0;
+        }
+    }
+    if (!merged) {
+        hipLaunchKernelGGL(k_edge_rows_vin, dim3(e.nwg), dim3(EDGE_BLOCK), 0, st, e, r, v, xk, pq, out, edge_partials, L.S_in);
+        return hipGetLastError();
+    }
+    return hipSuccess;
 }
 
 
@@ -1407,6 +1511,15 @@ __device__ __forceinline__ void scalar_update_body(KrylovScalars* S, const doubl
     } else if (step == STEP_SS) {   // red = ||s||^2
         S->rr[c] = red[c];
         S->early[c] = (red[c] <= S->tol2[c]) ? 1 : 0;
+    } else if (step == STEP_SS_TSTT) {   // red[4..5] = ||s||^2, red[0..1] = t.s, red[2..3] = t.t: STEP_SS, then STEP_TSTT
+        S->rr[c] = red[4 + c];
+        S->early[c] = (red[4 + c] <= S->tol2[c]) ? 1 : 0;
+        const double ts = red[c], tt = red[2 + c];
+        if (S->early[c]) S->omega[c] = 0.0;
+        else if (!(tt > tiny)) {
+            S->omega[c] = 0.0;
+            S->early[c] = 2;   // breakdown after this update
+        } else S->omega[c] = ts / tt;
     } else if (step == STEP_TSTT) {   // red[0..1] = t.s, red[2..3] = t.t
         const double ts = red[c], tt = red[2 + c];
         if (S->early[c]) S->omega[c] = 0.0;
@@ -1611,6 +1724,54 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_xr_update(LazyScalars L, double2*
 hipError_t launch_xr_update(const LazyScalars& S, double2* u, const double2* p_hat, const double2* s_hat, const double2* s, const double2* t, double2* r,
                             const double2* r_hat, int64_t n, double* partials, hipStream_t st) {
     hipLaunchKernelGGL(k_xr_update, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, S, u, p_hat, s_hat, s, t, r, r_hat, n, partials);
+    return hipGetLastError();
+}
+
+// k_xr_update with s = r - alpha v formed on the fly (it was never stored: k_apply_vin): r is read and written in place
+__global__ __launch_bounds__(VEC_BLOCK) void k_xr_update_vs(LazyScalars L, double2* __restrict__ u, const double2* __restrict__ p, const double2* __restrict__ v,
+                                                            const double2* __restrict__ t, double2* __restrict__ r, const double2* __restrict__ r_hat, int64_t n,
+                                                            double* partials) {
+    const KrylovScalars* S = lazy_scalars<VEC_BLOCK>(L);
+    const double ax = S->alpha[0], ay = S->alpha[1], ox = S->omega[0], oy = S->omega[1];
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * VEC_BLOCK;
+    for (int64_t i0 = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i0 < n; i0 += stride * VEC_UNROLL) {
+        double2 pi[VEC_UNROLL], ro[VEC_UNROLL], vi[VEC_UNROLL], ti[VEC_UNROLL], rh[VEC_UNROLL], ui[VEC_UNROLL];
+#pragma unroll
+        for (int q = 0; q < VEC_UNROLL; ++q) {
+            const int64_t i = min(i0 + q * stride, n - 1);
+            pi[q] = load_nt(p + i);
+            ro[q] = load_nt(r + i);
+            vi[q] = load_nt(v + i);
+            ti[q] = load_nt(t + i);
+            rh[q] = load_nt(r_hat + i);
+            ui[q] = load_nt(u + i);
+        }
+#pragma unroll
+        for (int q = 0; q < VEC_UNROLL; ++q) {
+            const int64_t i = i0 + q * stride;
+            if (i < n) {
+                const double2 si = make_double2(ro[q].x - ax * vi[q].x, ro[q].y - ay * vi[q].y);   // BiCGStab.zig:325-327
+                double2 un = ui[q];
+                un.x += ax * pi[q].x;   // BiCGStab.zig:329-331 (x += alpha * p_hat)
+                un.y += ay * pi[q].y;
+                un.x += ox * si.x;      // BiCGStab.zig:352-354 (x += omega * s_hat)
+                un.y += oy * si.y;
+                store_nt(u + i, un);
+                const double2 ri = make_double2(si.x - ox * ti[q].x, si.y - oy * ti[q].y);   // BiCGStab.zig:356-358
+                store_nt(r + i, ri);
+                acc[0] += rh[q].x * ri.x;
+                acc[1] += rh[q].y * ri.y;
+                acc[2] += ri.x * ri.x;
+                acc[3] += ri.y * ri.y;
+            }
+        }
+    }
+    block_partials<VEC_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
+}
+hipError_t launch_xr_update_vs(const LazyScalars& S, double2* u, const double2* p, const double2* v, const double2* t, double2* r, const double2* r_hat, int64_t n,
+                               double* partials, hipStream_t st) {
+    hipLaunchKernelGGL(k_xr_update_vs, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, S, u, p, v, t, r, r_hat, n, partials);
     return hipGetLastError();
 }
 

@@ -433,6 +433,9 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     // Krylov modes on a small single-process mesh: the scalar steps travel with the kernels that consume their result (LazyScalars,
     // tm_kernels.h) -- three partial-sum buffers in rotation, two scalar blocks
     lazy = !has_hooks && opt.inner != TM_INNER_RELAX && std::max(nwg_apply, nwg_vec) <= 512 && !(opt.flags & TM_OPT_EAGER_SCALARS);
+    // second apply of an iteration with the s-update folded in: single process (nothing of s has to travel) and no preconditioner
+    // (which wants s as a stored vector)
+    fuse_s = !has_hooks && opt.inner == TM_INNER_BICGSTAB && !(opt.flags & TM_OPT_EAGER_SCALARS);
     for (int k = 0; k < (lazy ? 3 : 1); ++k) part_buf[k] = arena.alloc_n<double>(npart);
     partials = part_buf[0];
     red = arena.alloc_n<double>(MAX_PARTIALS);
@@ -679,6 +682,29 @@ void Smoother::apply(const double2* in, double2* out, int mode, int dot, const d
     }
 }
 
+// t = D^-1 A (r - alpha v) with the s-update folded in (single-process handles without a preconditioner): see k_apply_vin
+void Smoother::apply_vin(const double2* rr, const double2* vv, double2* out) {
+    std::vector<ApplyBlock> blocks(lp.owned_blocks.size());
+    for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
+        const int64_t b = lp.owned_blocks[k];
+        const int64_t ls = lp.local_start[k];
+        ApplyBlock& a = blocks[k];
+        a.in = rr + ls;
+        a.in2 = vv + ls;
+        a.xk = X + ls;
+        a.pq = PQ ? PQ + ls : nullptr;
+        a.aux = nullptr;
+        a.out = out + ls;
+        a.ni = static_cast<int>(topo.ni[b]);
+        a.nj = static_cast<int>(topo.nj[b]);
+        a.omega = 0.0;
+        a.partials = partials + static_cast<size_t>(poff[k]) * MAX_PARTIALS;
+    }
+    HIPCHK(launch_apply_vin(blocks.data(), static_cast<int>(blocks.size()), edge, rr, vv, X, PQ, out, partials + static_cast<size_t>(poff_edge) * MAX_PARTIALS,
+                            scalars_for(), stream));
+    reduce_update(nwg_apply, STEP_SS_TSTT);
+}
+
 void Smoother::white_launch(int update) {
     WhiteArgs w;
     const auto idx = [&](int64_t b) { return lp.local_start[std::lower_bound(lp.owned_blocks.begin(), lp.owned_blocks.end(), b) - lp.owned_blocks.begin()]; };
@@ -754,6 +780,26 @@ int Smoother::picard_bicgstab(tm_stats& st) {
                 apply(p_hat, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0, STEP_SIGMA);
             } else {
                 apply(p, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0, STEP_SIGMA);
+            }
+            if (fuse_s) {
+                // s = r - alpha v is never stored: the second apply forms it as the rows enter its window (interior rows and
+                // perimeter rows), with ||s||^2 beside t.s and t.t in one reduction; k_xr_update_vs forms it again
+                apply_vin(r, v, t);
+                HIPCHK(launch_xr_update_vs(scalars_for(), U, p, v, t, r, r_hat, n_owned, partials, stream));
+                reduce_update(nwg_vec, STEP_RHO);
+                st.operator_sweeps += 2;
+                it_total += 1;
+                if (it_total % opt.check_every == 0 || it_total == opt.max_inner) {
+                    flush_pending();
+                    HIPCHK(hipMemcpyAsync(h_S, S, sizeof(KrylovScalars), hipMemcpyDeviceToHost, stream));
+                    sync();
+                    if (h_S->done[0] && h_S->done[1]) {
+                        converged = h_S->done[0] == 1 && h_S->done[1] == 1;
+                        breakdown = !converged;
+                        break;
+                    }
+                }
+                continue;
             }
             HIPCHK(launch_s_update(scalars_for(), r, v, s, n_owned, partials, stream));
             reduce_update(nwg_vec, STEP_SS);

@@ -144,6 +144,8 @@ struct Smoother {
     void reduce(int nwg);   // partials -> red (+ all-reduce)
     void reduce_update(int nwg, int step, double rtol = 0.0, double atol = 0.0);   // reduce + Krylov scalar update
     // lazy scalar steps (small single-process meshes): see LazyScalars in tm_kernels.h
+    bool fuse_s = false;            // k_apply_vin / k_xr_update_vs instead of k_s_update + apply + k_xr_update
+    void apply_vin(const double2* r, const double2* v, double2* out);
     bool lazy = false;
     double* part_buf[3] = {nullptr, nullptr, nullptr};
     int part_rot = 0;
