@@ -846,8 +846,8 @@ int Smoother::picard_bicgstab(tm_stats& st) {
 //   perimeter rows of X^(k+1)  <- perimeter-row kernel on X^k           (into M)
 //   interior rows of X^(k+2)   <- K2x2 (reads X^k and M's perimeter; leaves the first-interior ring of X^(k+1) in M)
 //   perimeter rows of X^(k+2)  <- perimeter-row kernel on M (perimeter + ring + exchanged ghost rows are all it reads)
-// With several ranks the K2x2 grid is launched in three parts so that both halo exchanges (of X^k, then of X^(k+1)) travel
-// while workgroups that touch neither perimeter nor ring are running.
+// With several ranks the K2x2 grid is launched in two parts on two queues (relax_pairs_pipelined): the border workgroups in the
+// latency-critical chain, the rest beside it.
 void Smoother::relax2_launch(int subset, bool counts, int dot, hipStream_t on) {
     if (!on) on = stream;
     std::vector<Relax2Block> blocks(lp.owned_blocks.size());
@@ -873,12 +873,9 @@ void Smoother::relax2_launch(int subset, bool counts, int dot, hipStream_t on) {
 // want_partials: only the pass whose displacement norms are read back pays for them (the last one of an iterate() call)
 void Smoother::relax_pair(bool want_partials) {
     const int dot = want_partials ? DOT_DELTA : DOT_NONE;
-    exchange(X);
-    exchange_finish();
+    // (a handle that gets here has no neighbouring rank -- relax_sweeps sends the others through relax_pairs_pipelined: nothing travels)
     HIPCHK(launch_edge_rows(edge_nf, X, X, PQ, nullptr, M, opt.omega, MODE_RELAX, DOT_NONE, partials, stream));
     relax2_launch(R2_ALL, true, dot);
-    exchange(M);
-    exchange_finish();
     HIPCHK(launch_edge_rows(edge_nf, M, M, PQ, nullptr, U, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, stream));
     std::swap(X, U);
 }
