@@ -419,7 +419,9 @@ def main():
                                               "so this figure may exceed the HBM peak -- it is not a bandwidth") if fused else "one sweep per launch: equals achieved",
                          "hbm_GBps_measured_traffic": (traffic / k2_avg_s / 1e9) if traffic else None,
                          "avg_launch_us": k2_avg_s * 1e6, "launches": k2_launches, "launches_timed": k2_timed,
-                         "timing": f"hipEvent pair around every {max(1, args.profile_every)}th launch of the kernel on the handle's stream, inside the timed region"},
+                         "timing": (f"hipEvent pairs on the handle's stream inside the timed region: around alternate groups of {max(1, args.profile_every)} consecutive "
+                                    "launches of the kernel where nothing else is launched between them (a block with fixed walls: an event record is a "
+                                    f"barrier packet of several us), else around every {max(1, args.profile_every)}th launch")},
         }
         if scaling == "strong":
             ref1 = None

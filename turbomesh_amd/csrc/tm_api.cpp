@@ -314,6 +314,8 @@ int tm_smoother_profile(tm_smoother* s, int enable) {
         s->impl.ev_used = 0;
         s->impl.prof_launches = 0;
         s->impl.prof_timed = 0;
+        s->impl.prof_phase = 0;
+        s->impl.prof_open = 0;
         return TM_OK;
     });
 }

@@ -614,6 +614,34 @@ void Smoother::profiled(const std::function<void()>& launch, bool counts, hipStr
         launch();
         return;
     }
+    auto next_events = [&]() {
+        if (ev_used == ev_start.size()) {
+            hipEvent_t e0, e1;
+            HIPCHK(hipEventCreate(&e0));
+            HIPCHK(hipEventCreate(&e1));
+            ev_start.push_back(e0);
+            ev_stop.push_back(e1);
+        }
+    };
+    // A handle whose passes follow each other with nothing in between (single process, no perimeter rows to evaluate: a block with
+    // fixed walls) is timed in GROUPS: one event pair around `profile` consecutive launches, every other group -- an event record is
+    // a barrier packet whose latency (several us here) would otherwise be charged to every single launch it brackets.
+    if (!has_hooks && edge_nf.nrows == 0 && counts && profile > 1) {
+        const uint64_t G = static_cast<uint64_t>(profile), pos = prof_phase % (2 * G);
+        if (pos == 0) {
+            next_events();
+            HIPCHK(hipEventRecord(ev_start[ev_used], on));
+            prof_open = 0;
+        }
+        launch();
+        prof_launches += 1;
+        prof_phase += 1;
+        if (pos < G) {
+            prof_open += 1;
+            if (pos == G - 1) profile_close(on);
+        }
+        return;
+    }
     // sampling: only every profile-th pass carries event pairs (two extra packets on the stream per pair).  The parts of a
     // split pass (inside: counts == false, then border: counts == true) see the same prof_launches, hence the same decision.
     const bool prof_sample = (prof_launches % static_cast<uint64_t>(profile)) == 0;
@@ -622,13 +650,7 @@ void Smoother::profiled(const std::function<void()>& launch, bool counts, hipStr
         if (counts) prof_launches += 1;
         return;
     }
-    if (ev_used == ev_start.size()) {
-        hipEvent_t e0, e1;
-        HIPCHK(hipEventCreate(&e0));
-        HIPCHK(hipEventCreate(&e1));
-        ev_start.push_back(e0);
-        ev_stop.push_back(e1);
-    }
+    next_events();
     HIPCHK(hipEventRecord(ev_start[ev_used], on));
     launch();
     HIPCHK(hipEventRecord(ev_stop[ev_used], on));
@@ -637,6 +659,15 @@ void Smoother::profiled(const std::function<void()>& launch, bool counts, hipStr
         prof_launches += 1;
         prof_timed += 1;
     }
+}
+
+// ends a group bracket (see profiled): after its last launch, or when the call that opened it runs out of launches
+void Smoother::profile_close(hipStream_t on) {
+    if (prof_open == 0) return;
+    HIPCHK(hipEventRecord(ev_stop[ev_used], on ? on : stream));
+    ev_used += 1;
+    prof_timed += prof_open;
+    prof_open = 0;
 }
 
 void Smoother::apply(const double2* in, double2* out, int mode, int dot, const double2* aux, const double2* xk, double omega, int step) {
@@ -1009,6 +1040,10 @@ void Smoother::relax_sweeps(uint64_t n, tm_stats& st) {
         st.operator_sweeps += 1;
         outer_done += 1;
     }
+    if (profile && prof_open) {   // a group bracket the call leaves open: close it behind its last launch; the next call starts a new one
+        profile_close(stream);
+        prof_phase = 0;
+    }
     if (n) {
         reduce(last_nwg);   // partial sums of the LAST sweep -> sum (x_old - x_new)^2, sum (y_old - y_new)^2
         HIPCHK(hipMemcpyAsync(h_red, red, sizeof(double) * MAX_PARTIALS, hipMemcpyDeviceToHost, stream));
@@ -1109,6 +1144,7 @@ void Smoother::profile_read(double* ms_total, uint64_t* launches, uint64_t* time
     ev_used = 0;
     prof_launches = 0;
     prof_timed = 0;
+    prof_phase = 0;
 }
 
 // ------------------------------------------------------------------ introspection

@@ -110,6 +110,9 @@ struct Smoother {
     size_t ev_used = 0;
     uint64_t prof_launches = 0;     // event pairs that count as a launch of the dominant kernel (the parts of a split K2x2 pass count once)
     uint64_t prof_timed = 0;        // ... of which carried an event pair
+    uint64_t prof_open = 0;         // launches inside the group bracket that is open (see profiled)
+    uint64_t prof_phase = 0;        // position within the bracketed / unbracketed alternation
+    void profile_close(hipStream_t on);
     void profile_read(double* ms_total, uint64_t* launches, uint64_t* timed);
 
     void create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm_control_fn* c, const tm_comm_hooks* h, void* strm,
