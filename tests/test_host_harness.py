@@ -67,3 +67,11 @@ def test_harness_handle_iterate_until_and_plot3d(tmp_path):
     # a format that is not built in answers like the reference without the cgns library
     r = subprocess.run([HARNESS, "single", "9", "9", "1", "bicgstab", "write", str(tmp_path / "m.cgns")], capture_output=True, text=True, timeout=120)
     assert r.returncode == 1 and "OutputFormatNotEnabled" in r.stderr
+
+
+@pytest.mark.gpu
+def test_harness_csr_slot_known_answer():
+    # seam 2 (solver.zig:40-93) from the compiled caller: umfpack.zig:71-97's system through tm_csr_solve
+    r = subprocess.run([HARNESS, "csr"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "csr kat: rc 0" in r.stdout

@@ -3,6 +3,7 @@
 //
 //   tm_harness strip <nblocks> <ni> <nj> <iterations> [relax|bicgstab|mg] [until <tol>] [write <file.xyz>] [dump.bin]
 //   tm_harness single <ni> <nj> <iterations> [relax|bicgstab|mg] [until <tol>] [write <file.xyz>] [dump.bin]
+//   tm_harness csr                                     the linear-solver slot (seam 2) on the reference's 5 x 5 known answer
 //
 // The synthetic edges are those of SURVEY.md 8d (config 2 / config 4), identical to turbomesh_amd/configs.py.
 // dump.bin (optional): all block coordinates as raw f64 after smoothing, for the parity test.
@@ -89,8 +90,32 @@ static discrete::Mesh buildSingle(std::size_t ni, std::size_t nj) {
     return mesh;
 }
 
+// Seam 2 from a compiled caller: a system assembled on the host -- here the reference's own known answer, umfpack.zig:71-97
+// (A x = b, x = 1..5, given there in CSC; CSR below) as the x-system and 2 b as the y-system -- solved through tm_csr_solve.
+static int csrKat() {
+    const int32_t Ap[] = {0, 2, 5, 8, 9, 12};     // rows: [2 3 . . .] [3 . 4 . 6] [. -1 -3 2 .] [. . 1 . .] [. 4 2 . 1]
+    const int32_t Ai[] = {0, 1, 0, 2, 4, 1, 2, 3, 2, 1, 2, 4};
+    const double Ax[] = {2, 3, 3, 4, 6, -1, -3, 2, 1, 4, 2, 1};
+    const double bx[] = {8, 45, -3, 3, 19};
+    double by[5], x[5] = {0, 0, 0, 0, 0}, y[5] = {0, 0, 0, 0, 0};
+    for (int i = 0; i < 5; ++i) by[i] = 2 * bx[i];
+    tm_solver_opt opt{};
+    opt.tag = TM_SOLVER_HIP;
+    opt.rtol = 1e-14;
+    opt.max_inner = 200;
+    opt.check_every = 1;
+    tm_stats st{};
+    const int rc = tm_csr_solve(5, Ap, Ai, Ax, nullptr, bx, by, x, y, &opt, &st);
+    if (rc < 0) throw core::Error(rc, tm_last_error());
+    double err = 0;
+    for (int i = 0; i < 5; ++i) err = std::fmax(err, std::fmax(std::fabs(x[i] - (i + 1)), std::fabs(y[i] - 2 * (i + 1))));
+    std::printf("csr kat: rc %d, inner iterations %llu, max error %.3e\n", rc, static_cast<unsigned long long>(st.inner_iterations), err);
+    return (rc == 0 && err < 1e-9) ? 0 : 1;
+}
+
 int main(int argc, char** argv) {
     try {
+        if (argc >= 2 && std::strcmp(argv[1], "csr") == 0) return csrKat();
         if (argc < 5) {
             std::fprintf(stderr, "usage: %s strip <nblocks> <ni> <nj> <iterations> [relax|bicgstab|mg] [until <tol>] [write <file.xyz>] [dump.bin]\n       %s single <ni> <nj> <iterations> [relax|bicgstab|mg] [until <tol>] [write <file.xyz>] [dump.bin]\n", argv[0], argv[0]);
             return 2;
