@@ -16,6 +16,9 @@ gold = os.path.join(ROOT, "tests", "golden")
 inp = Input.parse(open(os.path.join(gold, "examples", name, name + ".json")).read())
 mesh = inp.template.run(inp.geometry(gold), tfi=None)
 w = inp.wall_control_function.white
+if os.environ.get("TM_ROWS"):   # rows per K2 chunk (tm_tune_apply), for experiments
+    from turbomesh_amd import _capi
+    _capi.lib().tm_tune_apply(int(os.environ["TM_ROWS"]), 0, -1, -1)
 for rep in range(2):
     with smooth.Smoother(mesh, solver.Option.hip(rtol=rtol, max_inner=20000), wcf.Algorithm(wcf.White(w.ds_target, w.theta_target))) as sm:
         t0 = time.perf_counter()

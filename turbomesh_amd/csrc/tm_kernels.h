@@ -40,7 +40,11 @@ struct KrylovScalars;
 struct LazyScalars;
 
 struct ApplyBlock {
-    const double2* in2 = nullptr;   // VIN kernels: the operator acts on  in - alpha * in2  (s = r - alpha v, BiCGStab.zig:325-327) formed on the fly
+    // virtual-input kernels (launch_apply_virtual): the operator acts on a vector formed on the fly from in, in2, in3
+    const double2* in2 = nullptr;
+    const double2* in3 = nullptr;
+    double2* pout = nullptr;        // VK_P: where the formed vector is stored (owned rows)
+    int rows = 0;                   // rows per chunk; 0 = the per-block rule (rows_per_chunk, tm_kernels.hip)
     const double2* in;    // vector the operator acts on, pointing at the block's node (0,0)
     const double2* xk;    // frozen coordinates the coefficients are built from (== in for field mode)
     const double2* pq;    // control function (P,Q) or nullptr (Laplace)
@@ -51,7 +55,7 @@ struct ApplyBlock {
     double* partials;     // [nwg * MAX_PARTIALS] for this launch
 };
 // number of workgroups k2 launches for a block (also the number of partial rows it writes)
-int apply_block_nwg(int ni, int nj);
+int apply_block_nwg(int ni, int nj, int rows = 0);
 void tune_apply(int rows_per_chunk, int unroll, int pipe, int nt);   // <=0 (pipe, nt: <0) keeps the current value
 hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_t stream);
 // several blocks of one rank in one launch (per group of APPLY_BATCH_MAX); block k's partial sums go to blocks[k].partials
@@ -135,11 +139,21 @@ hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const doubl
 // interior rows of n <= APPLY_BATCH_MAX blocks + the perimeter rows in one launch (Krylov modes); hipErrorNotSupported = no such kernel
 hipError_t launch_apply_edge_blocks(const ApplyBlock* blocks, int n, int mode, int dot, const EdgeRowsDev& e, const double2* in, const double2* xk,
                                     const double2* pq, const double2* aux, double2* out, double* edge_partials, hipStream_t stream);
-// Second apply of a BiCGStab iteration with the s-update folded in (single process): t = D^-1 A (r - alpha v), s never stored.
-// Interior rows of all blocks (one launch per group of APPLY_BATCH_MAX) and the perimeter rows; alpha from `scal` (pending steps
-// applied by the first kernel that runs).  Partial sums: DOT_IN_SS.
-hipError_t launch_apply_vin(const ApplyBlock* blocks, int n, const EdgeRowsDev& e, const double2* r, const double2* v, const double2* xk, const double2* pq,
-                            double2* out, double* edge_partials, const LazyScalars& scal, hipStream_t stream);
+// An apply of a BiCGStab iteration with the vector update in front of it folded in (single process):
+//   kind 1 (s):  out = D^-1 A (in - alpha in2)                         s never stored; partial sums DOT_IN_SS
+//   kind 2 (p):  out = D^-1 A p',  p' = in + beta (in2 - omega in3)    p' stored to pout (a different array than in2); partial sums
+//                DOT_AUX with aux
+// in = r; (in2, in3) = (v, -) or (p, v).  Rank-local vectors; blocks[k].in/in2/in3/pout point at the block's node (0,0).
+// Interior rows of all blocks (one launch per group of APPLY_BATCH_MAX) and the perimeter rows; the scalars come from `scal`
+// (pending steps applied by the first kernel that runs).
+constexpr int VK_NONE = 0, VK_S = 1, VK_P = 2;
+struct VirtualIn {
+    int kind;
+    const double2 *in, *in2, *in3, *aux;
+    double2* pout;
+};
+hipError_t launch_apply_virtual(const ApplyBlock* blocks, int n, const EdgeRowsDev& e, const VirtualIn& V, const double2* xk, const double2* pq, double2* out,
+                                double* edge_partials, const LazyScalars& scal, hipStream_t stream);
 // b (unscaled) per perimeter row scattered into a dense vector that was zeroed by the caller; scaled!=0 writes D^-1 b
 hipError_t launch_edge_rhs(const EdgeRowsDev& e, const double2* xk, const double2* pq, double2* rhs_out, int scaled,
                            double* partials /* [nwg*MAX_PARTIALS]: sum (D^-1 b)^2 x,y */, hipStream_t stream);

@@ -227,6 +227,7 @@ __device__ __forceinline__ const KrylovScalars* lazy_scalars(const LazyScalars& 
 // K2  winslow_apply: interior rows of one block (replaces smooth.zig:923-992 fill +
 //     BiCGStab.zig:424-435 mat-vec), matrix-free, factored row evaluation (winslow_row)
 // ------------------------------------------------------------------------------------------
+static bool g_rows_forced = false;   // tm_tune_apply chose the chunk length: no per-block rule
 static int g_rows_per_chunk = 18;   // tunable (tm_tune_apply); short chunks: see relax2_rows_per_chunk
 static int g_unroll = 6;   // rows per load group: 3 or 6
 static int g_nt = 1;
@@ -240,10 +241,22 @@ __device__ __forceinline__ void store_nt(double2* dst, double2 v) {
     __builtin_nontemporal_store(o, reinterpret_cast<d2v*>(dst));
 }
 
+// The vector a Krylov update would have stored, formed where it is consumed (the expressions of k_s_update / k_p_update; the
+// library is built with -ffp-contract=off, so they give the same bits wherever they are formed)
+template <int VK>
+__device__ __forceinline__ double2 virtual_vec(double2 x, double2 y, double2 z, double2 va, double2 vb) {
+    if (VK == VK_S) return make_double2(x.x - va.x * y.x, x.y - va.y * y.y);   // s = r - alpha v (BiCGStab.zig:325-327)
+    if (VK == VK_P) return make_double2(x.x + va.x * (y.x - vb.x * z.x), x.y + va.y * (y.y - vb.y * z.y));   // p = r + beta (p - omega v) (BiCGStab.zig:310-312)
+    return x;
+}
+
 // One workgroup's tile of one block; `bid` = the workgroup's index within that block's tiles (also its partial-sum slot).
-// VIN: the operator acts on the vector  in - alpha * in2  (component-wise alpha = va) formed as the rows are taken into the window
-template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool NT, bool VIN = false>
-__device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG, int nRC, int bid, double2 va = make_double2(0.0, 0.0)) {
+// VK (virtual input vector, formed as the rows are taken into the window; va, vb component-wise):
+//   VK_S: in - va * in2                (s = r - alpha v, never stored)
+//   VK_P: in + va * (in2 - vb * in3)   (p = r + beta (p - omega v), stored to a.pout for the owned rows)
+template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool NT, int VK = VK_NONE>
+__device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG, int nRC, int bid, double2 va = make_double2(0.0, 0.0),
+                                           double2 vb = make_double2(0.0, 0.0)) {
     static_assert(U % 3 == 0, "the 3-row window rotates by renaming: the row group must be a multiple of 3");
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -278,19 +291,23 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
         // 3-row window of the vector, rotating by index: slot (r % 3) holds row i0-1+r as (value, e = right - left, h = right + left)
         double2 Wc[3], We[3], Wh[3];
         double2 Xc[3], Xdet = make_double2(0.0, 0.0);   // frozen coordinates when they are a different array; Xdet of the centre row
-        auto comb = [&](double2 x, double2 y) { return make_double2(x.x - va.x * y.x, x.y - va.y * y.y); };   // BiCGStab.zig:325-327, k_s_update's expression
+        auto comb = [&](double2 x, double2 y, double2 z) { return virtual_vec<VK>(x, y, z, va, vb); };
         {
             double2 h0, h1;
             load_row(a.in, i0 - 1, Wc[0], h0);
             load_row(a.in, i0, Wc[1], h1);
-            if (VIN) {
-                double2 q0, g0, q1, g1;
+            if (VK != VK_NONE) {
+                double2 q0, g0, q1, g1, z0 = make_double2(0.0, 0.0), y0 = z0, z1 = z0, y1 = z0;
                 load_row(a.in2, i0 - 1, q0, g0);
                 load_row(a.in2, i0, q1, g1);
-                Wc[0] = comb(Wc[0], q0);
-                h0 = comb(h0, g0);
-                Wc[1] = comb(Wc[1], q1);
-                h1 = comb(h1, g1);
+                if (VK == VK_P) {
+                    load_row(a.in3, i0 - 1, z0, y0);
+                    load_row(a.in3, i0, z1, y1);
+                }
+                Wc[0] = comb(Wc[0], q0, z0);
+                h0 = comb(h0, g0, y0);
+                Wc[1] = comb(Wc[1], q1, z1);
+                h1 = comb(h1, g1, y1);
             }
             const double2 l0 = lane_prev(h0, Wc[0]), r0 = lane_next(h0, Wc[0]), l1 = lane_prev(h1, Wc[1]), r1 = lane_next(h1, Wc[1]);
             We[0] = sub2(r0, l0); Wh[0] = add2(r0, l0);
@@ -306,7 +323,7 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
         }
 
         struct Group {
-            double2 pc[U], ph[U], xpc[U], xph[U], pqv[U], auxv[U], qc[VIN ? U : 1], qh[VIN ? U : 1];
+            double2 pc[U], ph[U], xpc[U], xph[U], pqv[U], auxv[U], qc[VK != VK_NONE ? U : 1], qh[VK != VK_NONE ? U : 1], zc[VK == VK_P ? U : 1], zh[VK == VK_P ? U : 1];
         };
         auto load_group = [&](int ib, Group& g) {   // rows ib+1 .. ib+U of the vector (and of xk), pq/aux of rows ib .. ib+U-1
 #pragma unroll
@@ -317,7 +334,8 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
                     g.ph[u] = Wh[1];
                 } else
                     load_row(a.in, prow, g.pc[u], g.ph[u]);
-                if (VIN) load_row(a.in2, prow, g.qc[u], g.qh[u]);
+                if (VK != VK_NONE) load_row(a.in2, prow, g.qc[u], g.qh[u]);
+                if (VK == VK_P) load_row(a.in3, prow, g.zc[u], g.zh[u]);
                 if (!FIELD) load_row(a.xk, prow, g.xpc[u], g.xph[u]);
                 const size_t cur = static_cast<size_t>(min(ib + u, ni - 2)) * nj + jc;
                 if (HAS_PQ) g.pqv[u] = a.pq[cur];
@@ -331,7 +349,8 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
             for (int u = 0; u < U; ++u) {
                 const int M = u % 3, C = (u + 1) % 3, P3 = (u + 2) % 3;   // window slots of rows i-1, i, i+1
                 const int row = ib + u;
-                const double2 nc = VIN ? comb(g.pc[u], g.qc[u]) : g.pc[u], nh = VIN ? comb(g.ph[u], g.qh[u]) : g.ph[u];
+                const double2 nc = VK != VK_NONE ? comb(g.pc[u], g.qc[u], g.zc[VK == VK_P ? u : 0]) : g.pc[u];
+                const double2 nh = VK != VK_NONE ? comb(g.ph[u], g.qh[u], g.zh[VK == VK_P ? u : 0]) : g.ph[u];
                 Wc[P3] = nc;
                 {
                     const double2 l = lane_prev(nh, nc), r = lane_next(nh, nc);
@@ -382,6 +401,7 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
                     } else {
                         *dst = o;
                     }
+                    if (VK == VK_P) store_nt(a.pout + static_cast<size_t>(row) * nj + j, Wc[C]);
                     accumulate<DOT>(acc, Wc[C], o, (DOT == DOT_AUX || DOT == DOT_AUX2) ? g.auxv[u] : ((DOT == DOT_DELTA) ? delta : o));
                 }
                 if (!FIELD) Xdet = sub2(lane_next(g.xph[u], g.xpc[u]), lane_prev(g.xph[u], g.xpc[u]));   // of the next centre row (= row i+1)
@@ -780,15 +800,25 @@ hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_c
 }
 void tune_fuse_rows(int rows) { g_fuse_rows = rows > 0 ? rows : 0; }
 
-static inline int rows_per_chunk(int ni) {
+// Rows per chunk of K2.  A block that cannot fill the device is bound by the chain of dependent row-group loads in each wave
+// (a round trip per 3 rows), not by bandwidth: it gets the shortest chunks (multiples of the 3-row load group) that keep the launch
+// within one round of workgroups (T106, 8 blocks of 10^2..10^4 nodes: 42.5 -> 29.7 us per BiCGStab iteration with 3 rows instead
+// of 18).  `rows` > 0: the caller's choice (a handle that looked at all of its blocks, Smoother::create).
+static inline int rows_per_chunk(int ni, int nj, int rows = 0) {
     const int interior = ni - 2;
-    int RI = g_rows_per_chunk;
+    int RI = rows > 0 ? rows : g_rows_per_chunk;
+    if (rows <= 0 && !g_rows_forced) {
+        const int nSG = (nj + 255) / 256;
+        int r = 3;
+        while (r < RI && nSG * ((interior + r - 1) / r) > 256) r += 3;
+        RI = std::min(RI, r);
+    }
     if (RI > interior) RI = interior;
     if (RI < 1) RI = 1;
     return RI;
 }
-int apply_block_nwg(int ni, int nj) {
-    const int RI = rows_per_chunk(ni);
+int apply_block_nwg(int ni, int nj, int rows) {
+    const int RI = rows_per_chunk(ni, nj, rows);
     const int nSG = (nj + 255) / 256;
     const int nRC = (ni - 2 + RI - 1) / RI;
     return nSG * nRC;
@@ -798,7 +828,7 @@ template <int MODE, int DOT, bool FIELD, bool HAS_PQ>
 static hipError_t launch_apply_u(const ApplyBlock& a, int RI, int nSG, int nRC, hipStream_t st) {
     const dim3 grid(nSG * nRC), block(256);
 #define TM_K2(U_, N_) hipLaunchKernelGGL((k_apply<MODE, DOT, FIELD, HAS_PQ, U_, N_>), grid, block, 0, st, a, RI, nSG, nRC)
-    if (g_unroll >= 6) {
+    if (g_unroll >= 6 && RI >= 6) {
         if (g_nt) TM_K2(6, true); else TM_K2(6, false);
     } else {
         if (g_nt) TM_K2(3, true); else TM_K2(3, false);
@@ -845,7 +875,7 @@ hipError_t launch_apply_blocks(const ApplyBlock* blocks, int n, int mode, int do
             if (a.ni < 3 || a.nj < 3) continue;   // no interior rows
             const int q = B.n++;
             B.b[q] = a;
-            B.RI[q] = rows_per_chunk(a.ni);
+            B.RI[q] = rows_per_chunk(a.ni, a.nj, a.rows);
             B.nSG[q] = (a.nj + 255) / 256;
             B.nRC[q] = (a.ni - 2 + B.RI[q] - 1) / B.RI[q];
             B.start[q] = total;
@@ -872,7 +902,7 @@ hipError_t launch_apply_blocks(const ApplyBlock* blocks, int n, int mode, int do
 
 hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_t st) {
     if (a.ni < 3 || a.nj < 3) return hipSuccess;   // no interior rows
-    const int RI = rows_per_chunk(a.ni);
+    const int RI = rows_per_chunk(a.ni, a.nj, a.rows);
     const int nSG = (a.nj + 255) / 256;
     const int nRC = (a.ni - 2 + RI - 1) / RI;
     // the (mode, dot) pairs the smoother uses
@@ -903,7 +933,10 @@ hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_
 }
 
 void tune_apply(int rows, int unroll, int pipe, int nt) {
-    if (rows > 0) g_rows_per_chunk = rows;
+    if (rows > 0) {
+        g_rows_per_chunk = rows;
+        g_rows_forced = true;
+    }
     if (unroll > 0) g_unroll = unroll;
     (void)pipe;
     if (nt >= 0) g_nt = nt;
@@ -1013,26 +1046,29 @@ __device__ __forceinline__ void edge_row_eval(const EdgeRun& R, const double* __
 }
 
 // Workgroup `wg` of a perimeter-row pass; `tid` = thread within it (threads >= EDGE_BLOCK of a wider block idle).
-template <int MODE, int DOT, bool VIN = false>
+template <int MODE, int DOT, int VK = VK_NONE>
 __device__ __forceinline__ void edge_rows_wg(const EdgeRowsDev& e, int wg, int tid, const double2* __restrict__ in, const double2* __restrict__ xk,
                                              const double2* __restrict__ pq, const double2* __restrict__ aux, double2* __restrict__ out, double omega,
-                                             double (&acc)[MAX_PARTIALS], const double2* __restrict__ in2 = nullptr, double2 va = make_double2(0.0, 0.0)) {
+                                             double (&acc)[MAX_PARTIALS], const double2* __restrict__ in2 = nullptr, double2 va = make_double2(0.0, 0.0),
+                                             const double2* __restrict__ in3 = nullptr, double2 vb = make_double2(0.0, 0.0), double2* __restrict__ pout = nullptr) {
     // one workgroup = one stretch of one run: everything read through R is workgroup-uniform (scalar loads)
     const EdgeRun& R = e.runs[__builtin_amdgcn_readfirstlane(e.wg_run[wg])];
     const int k = __builtin_amdgcn_readfirstlane(e.wg_k0[wg]) + tid;
     if (tid < EDGE_BLOCK && k < R.count) {
         double2 o;
         int row;
-        // VIN: the vector is  in - alpha * in2  formed on the fly (same expression as k_s_update)
+        // VK: the vector is formed on the fly (virtual_vec); VK_P also stores it for the row's own node
         auto vec = [&](int id) {
             const double2 x = in[id];
-            if (!VIN) return x;
+            if (VK == VK_NONE) return x;
             const double2 y = in2[id];
-            return make_double2(x.x - va.x * y.x, x.y - va.y * y.y);
+            const double2 z = VK == VK_P ? in3[id] : y;
+            return virtual_vec<VK>(x, y, z, va, vb);
         };
         edge_row_eval<MODE, DOT>(R, e.rhs, k, [&](int, int id) { return vec(id); }, [&](int, int id) { return xk[id]; }, [&](int id) { return vec(id); }, pq, aux,
                                  omega, acc, o, row);
         out[row] = o;
+        if (VK == VK_P) pout[row] = vec(row);
     }
 }
 
@@ -1068,35 +1104,52 @@ __global__ __launch_bounds__(256) void k_apply_edge_batch(ApplyBatch B, int tota
     if (DOT != DOT_NONE) block_partials<256>(acc, edge_partials + static_cast<size_t>(wg) * MAX_PARTIALS);   // waves 2, 3 add exact zeros
 }
 
-// Second apply of a BiCGStab iteration with the s-update folded in: t = D^-1 A s, s = r - alpha v formed as the rows enter the
-// window (b.in = r, b.in2 = v), partial sums t.s, t.t and ||s||^2 (DOT_IN_SS); s itself is never stored -- k_xr_update_vs forms it
-// again.  alpha comes from the scalar block, advanced by the pending steps where there are any (LazyScalars).
-// total_interior < 0: interior rows only (the perimeter rows follow in k_edge_rows_vin: large meshes).
-template <bool HAS_PQ>
-__global__ __launch_bounds__(256) void k_apply_vin(ApplyBatch B, int total_interior, EdgeRowsDev e, const double2* __restrict__ r, const double2* __restrict__ v,
-                                                   const double2* __restrict__ xk, const double2* __restrict__ pq, double2* __restrict__ out,
-                                                   double* edge_partials, LazyScalars L) {
+// An apply of a BiCGStab iteration with the vector update in front of it folded in (VirtualIn, tm_kernels.h):
+//   VK_S  second apply: t = D^-1 A s, s = r - alpha v formed as the rows enter the window; partial sums t.s, t.t and ||s||^2
+//         (DOT_IN_SS); s itself is never stored -- k_xr_update_vs forms it again.
+//   VK_P  first apply: v' = D^-1 A p', p' = r + beta (p - omega v) formed the same way AND stored (V.pout: the next iteration and
+//         k_xr_update_vs read it); partial sums r_hat . v' (DOT_AUX).  p' and v' are new arrays: neighbouring workgroups still
+//         read the old p and v in their halos.
+// The scalars come from the scalar block, advanced by the pending steps where there are any (LazyScalars).
+// total_interior < 0: interior rows only (the perimeter rows follow in k_edge_rows_vk: large meshes).
+template <int VK>
+__device__ __forceinline__ void virtual_scalars(const KrylovScalars* S, double2& va, double2& vb) {
+    if (VK == VK_S) {
+        va = make_double2(S->alpha[0], S->alpha[1]);
+        vb = make_double2(0.0, 0.0);
+    } else {
+        va = make_double2(S->beta[0], S->beta[1]);
+        vb = make_double2(S->omega[0], S->omega[1]);
+    }
+}
+template <bool HAS_PQ, int VK>
+__global__ __launch_bounds__(256) void k_apply_vk(ApplyBatch B, int total_interior, EdgeRowsDev e, VirtualIn V, const double2* __restrict__ xk,
+                                                  const double2* __restrict__ pq, double2* __restrict__ out, double* edge_partials, LazyScalars L) {
+    constexpr int DOT = VK == VK_S ? DOT_IN_SS : DOT_AUX;
     const KrylovScalars* S = lazy_scalars<256>(L);
-    const double2 va = make_double2(S->alpha[0], S->alpha[1]);
+    double2 va, vb;
+    virtual_scalars<VK>(S, va, vb);
     if (total_interior < 0 || static_cast<int>(blockIdx.x) < total_interior) {   // workgroup-uniform
         int k = 0;
 #pragma unroll
         for (int q = 1; q < APPLY_BATCH_MAX; ++q)
             if (q < B.n && static_cast<int>(blockIdx.x) >= B.start[q]) k = q;
-        apply_tile<MODE_SCALED, DOT_IN_SS, false, HAS_PQ, 3, true, true>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], static_cast<int>(blockIdx.x) - B.start[k], va);
+        apply_tile<MODE_SCALED, DOT, false, HAS_PQ, 3, true, VK>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], static_cast<int>(blockIdx.x) - B.start[k], va, vb);
         return;
     }
     const int wg = static_cast<int>(blockIdx.x) - total_interior;
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
-    edge_rows_wg<MODE_SCALED, DOT_IN_SS, true>(e, wg, threadIdx.x, r, xk, pq, nullptr, out, 0.0, acc, v, va);
+    edge_rows_wg<MODE_SCALED, DOT, VK>(e, wg, threadIdx.x, V.in, xk, pq, V.aux, out, 0.0, acc, V.in2, va, V.in3, vb, V.pout);
     block_partials<256>(acc, edge_partials + static_cast<size_t>(wg) * MAX_PARTIALS);
 }
-__global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows_vin(EdgeRowsDev e, const double2* __restrict__ r, const double2* __restrict__ v,
-                                                              const double2* __restrict__ xk, const double2* __restrict__ pq, double2* __restrict__ out,
-                                                              double* partials, const KrylovScalars* __restrict__ S) {
-    const double2 va = make_double2(S->alpha[0], S->alpha[1]);
+template <int VK>
+__global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows_vk(EdgeRowsDev e, VirtualIn V, const double2* __restrict__ xk, const double2* __restrict__ pq,
+                                                             double2* __restrict__ out, double* partials, const KrylovScalars* __restrict__ S) {
+    constexpr int DOT = VK == VK_S ? DOT_IN_SS : DOT_AUX;
+    double2 va, vb;
+    virtual_scalars<VK>(S, va, vb);
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
-    edge_rows_wg<MODE_SCALED, DOT_IN_SS, true>(e, blockIdx.x, threadIdx.x, r, xk, pq, nullptr, out, 0.0, acc, v, va);
+    edge_rows_wg<MODE_SCALED, DOT, VK>(e, blockIdx.x, threadIdx.x, V.in, xk, pq, V.aux, out, 0.0, acc, V.in2, va, V.in3, vb, V.pout);
     block_partials<EDGE_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
 
@@ -1137,7 +1190,7 @@ hipError_t launch_apply_edge_blocks(const ApplyBlock* blocks, int n, int mode, i
         if (a.ni < 3 || a.nj < 3) continue;
         const int q = B.n++;
         B.b[q] = a;
-        B.RI[q] = rows_per_chunk(a.ni);
+        B.RI[q] = rows_per_chunk(a.ni, a.nj, a.rows);
         B.nSG[q] = (a.nj + 255) / 256;
         B.nRC[q] = (a.ni - 2 + B.RI[q] - 1) / B.RI[q];
         B.start[q] = total;
@@ -1159,9 +1212,9 @@ hipError_t launch_apply_edge_blocks(const ApplyBlock* blocks, int n, int mode, i
     return hipErrorNotSupported;
 }
 
-hipError_t launch_apply_vin(const ApplyBlock* blocks, int n, const EdgeRowsDev& e, const double2* r, const double2* v, const double2* xk, const double2* pq,
-                            double2* out, double* edge_partials, const LazyScalars& scal, hipStream_t st) {
-    if (e.nrows == 0) return hipErrorInvalidValue;
+hipError_t launch_apply_virtual(const ApplyBlock* blocks, int n, const EdgeRowsDev& e, const VirtualIn& V, const double2* xk, const double2* pq, double2* out,
+                                double* edge_partials, const LazyScalars& scal, hipStream_t st) {
+    if (e.nrows == 0 || (V.kind != VK_S && V.kind != VK_P)) return hipErrorInvalidValue;
     const bool has_pq = pq != nullptr;
     const bool merged = n <= APPLY_BATCH_MAX;   // one launch for everything; else interior groups first, perimeter rows last
     LazyScalars L = scal;
@@ -1174,7 +1227,7 @@ hipError_t launch_apply_vin(const ApplyBlock* blocks, int n, const EdgeRowsDev& 
             if (a.ni < 3 || a.nj < 3) continue;
             const int q = B.n++;
             B.b[q] = a;
-            B.RI[q] = rows_per_chunk(a.ni);
+            B.RI[q] = rows_per_chunk(a.ni, a.nj, a.rows);
             B.nSG[q] = (a.nj + 255) / 256;
             B.nRC[q] = (a.ni - 2 + B.RI[q] - 1) / B.RI[q];
             B.start[q] = total;
@@ -1184,8 +1237,15 @@ hipError_t launch_apply_vin(const ApplyBlock* blocks, int n, const EdgeRowsDev& 
         const dim3 grid(merged ? total + e.nwg : total), block(256);
         if (grid.x == 0) continue;
         const int ti = merged ? total : -1;
-        if (has_pq) hipLaunchKernelGGL((k_apply_vin<true>), grid, block, 0, st, B, ti, e, r, v, xk, pq, out, edge_partials, L);
-        else hipLaunchKernelGGL((k_apply_vin<false>), grid, block, 0, st, B, ti, e, r, v, xk, pq, out, edge_partials, L);
+#define TM_VK(PQ, K) hipLaunchKernelGGL((k_apply_vk<PQ, K>), grid, block, 0, st, B, ti, e, V, xk, pq, out, edge_partials, L)
+        if (V.kind == VK_S) {
+            if (has_pq) TM_VK(true, VK_S);
+            else TM_VK(false, VK_S);
+        } else {
+            if (has_pq) TM_VK(true, VK_P);
+            else TM_VK(false, VK_P);
+        }
+#undef TM_VK
         const hipError_t rc = hipGetLastError();
         if (rc != hipSuccess) return rc;
         if (L.nsteps) {   // the first launch has applied and published the pending steps: later ones read the published block
@@ -1195,7 +1255,8 @@ hipError_t launch_apply_vin(const ApplyBlock* blocks, int n, const EdgeRowsDev& 
         }
     }
     if (!merged) {
-        hipLaunchKernelGGL(k_edge_rows_vin, dim3(e.nwg), dim3(EDGE_BLOCK), 0, st, e, r, v, xk, pq, out, edge_partials, L.S_in);
+        if (V.kind == VK_S) hipLaunchKernelGGL(k_edge_rows_vk<VK_S>, dim3(e.nwg), dim3(EDGE_BLOCK), 0, st, e, V, xk, pq, out, edge_partials, L.S_in);
+        else hipLaunchKernelGGL(k_edge_rows_vk<VK_P>, dim3(e.nwg), dim3(EDGE_BLOCK), 0, st, e, V, xk, pq, out, edge_partials, L.S_in);
         return hipGetLastError();
     }
     return hipSuccess;

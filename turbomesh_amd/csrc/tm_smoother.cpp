@@ -121,6 +121,10 @@ void Smoother::sync() { HIPCHK(hipStreamSynchronize(stream)); }
 Smoother::~Smoother() {
     if (counted) g_multirank_handles.fetch_sub(1);
     if (h_S) (void)hipHostFree(h_S);
+    for (int k = 0; k < 2; ++k) {
+        if (h_poll[k]) (void)hipHostFree(h_poll[k]);
+        if (ev_poll[k]) (void)hipEventDestroy(ev_poll[k]);
+    }
     if (h_red) (void)hipHostFree(h_red);
     if (h_flags) (void)hipHostFree(h_flags);
     for (hipEvent_t e : ev_start) (void)hipEventDestroy(e);
@@ -403,14 +407,27 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     }
 
     // ---- reductions
+    // K2 chunk length for this handle: several small blocks in one launch -- the shortest chunks (multiples of the 3-row load
+    // group) that keep interior + perimeter workgroups within what the lazy scalar steps allow (512 partial rows); a single block
+    // and large meshes: the per-block rule of tm_kernels.hip (apply_rows = 0)
+    const int edge_wg = (opt.inner == TM_INNER_RELAX ? edge_nf.nwg : edge.nwg);   // a relax handle only ever launches the non-fixed rows
+    apply_rows = 0;
+    if (lp.owned_blocks.size() > 1) {
+        for (int r = 3; r < 18 && !apply_rows; r += 3) {
+            int total = edge_wg;
+            for (int64_t b : lp.owned_blocks) total += apply_block_nwg(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), r);
+            if (total <= 512) apply_rows = r;
+        }
+    }
+    if (const char* e = std::getenv("TM_APPLY_ROWS")) apply_rows = std::max(0, std::atoi(e));
     poff.clear();
     int off = 0;
     for (int64_t b : lp.owned_blocks) {
         poff.push_back(off);
-        off += apply_block_nwg(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
+        off += apply_block_nwg(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), apply_rows);
     }
     poff_edge = off;
-    off += (opt.inner == TM_INNER_RELAX ? edge_nf.nwg : edge.nwg);   // a relax handle only ever launches the non-fixed rows
+    off += edge_wg;
     nwg_apply = off;
     if (fuse_pairs) {
         poff2.clear();
@@ -436,6 +453,13 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     // second apply of an iteration with the s-update folded in: single process (nothing of s has to travel) and no preconditioner
     // (which wants s as a stored vector)
     fuse_s = !has_hooks && opt.inner == TM_INNER_BICGSTAB && !(opt.flags & TM_OPT_EAGER_SCALARS);
+    // ... and the first apply with the p-update folded in: p and v alternate between two arrays each (see k_apply_vk)
+    fuse_p = fuse_s;
+    if (const char* e = std::getenv("TM_FUSE_P")) fuse_p = fuse_p && std::atoi(e) != 0;
+    if (fuse_p) {
+        p_alt = arena.alloc_n<double2>(static_cast<uint64_t>(n_local));
+        v_alt = arena.alloc_n<double2>(static_cast<uint64_t>(n_local));
+    }
     for (int k = 0; k < (lazy ? 3 : 1); ++k) part_buf[k] = arena.alloc_n<double>(npart);
     partials = part_buf[0];
     red = arena.alloc_n<double>(MAX_PARTIALS);
@@ -453,6 +477,13 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     if (measure) return;
 
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_S), sizeof(KrylovScalars), hipHostMallocDefault));
+    pipelined_poll = lazy;   // small single-process meshes (see poll_done)
+    if (const char* e = std::getenv("TM_PIPELINED_POLL")) pipelined_poll = pipelined_poll && std::atoi(e) != 0;
+    if (pipelined_poll)
+        for (int k = 0; k < 2; ++k) {
+            HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_poll[k]), sizeof(KrylovScalars), hipHostMallocDefault));
+            HIPCHK(hipEventCreateWithFlags(&ev_poll[k], hipEventDisableTiming));
+        }
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_red), sizeof(double) * MAX_PARTIALS, hipHostMallocDefault));
     HIPCHK(hipMemsetAsync(S_buf[0], 0, sizeof(KrylovScalars), stream));
     if (S_buf[1] != S_buf[0]) HIPCHK(hipMemsetAsync(S_buf[1], 0, sizeof(KrylovScalars), stream));
@@ -685,6 +716,7 @@ void Smoother::apply(const double2* in, double2* out, int mode, int dot, const d
         a.ni = static_cast<int>(topo.ni[b]);
         a.nj = static_cast<int>(topo.nj[b]);
         a.omega = omega;
+        a.rows = apply_rows;
         a.partials = partials + static_cast<size_t>(poff[k]) * MAX_PARTIALS;
     }
     // Small meshes on a single-process handle: interior rows of all blocks AND the perimeter rows in one launch (no exchange has to
@@ -713,27 +745,39 @@ void Smoother::apply(const double2* in, double2* out, int mode, int dot, const d
     }
 }
 
-// t = D^-1 A (r - alpha v) with the s-update folded in (single-process handles without a preconditioner): see k_apply_vin
-void Smoother::apply_vin(const double2* rr, const double2* vv, double2* out) {
+// An apply with the vector update in front of it folded in (single-process handles without a preconditioner): see k_apply_vk.
+//   VK_S: out = D^-1 A (in - alpha in2)                       -> STEP_SS_TSTT
+//   VK_P: out = D^-1 A p', p' = in + beta (in2 - omega in3) stored to pout; r_hat . out -> STEP_SIGMA
+void Smoother::apply_virtual(int kind, const double2* in, const double2* in2, const double2* in3, double2* pout, double2* out) {
     std::vector<ApplyBlock> blocks(lp.owned_blocks.size());
     for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
         const int64_t b = lp.owned_blocks[k];
         const int64_t ls = lp.local_start[k];
         ApplyBlock& a = blocks[k];
-        a.in = rr + ls;
-        a.in2 = vv + ls;
+        a.in = in + ls;
+        a.in2 = in2 + ls;
+        a.in3 = in3 ? in3 + ls : nullptr;
+        a.pout = pout ? pout + ls : nullptr;
         a.xk = X + ls;
         a.pq = PQ ? PQ + ls : nullptr;
-        a.aux = nullptr;
+        a.aux = kind == VK_P ? r_hat + ls : nullptr;
         a.out = out + ls;
         a.ni = static_cast<int>(topo.ni[b]);
         a.nj = static_cast<int>(topo.nj[b]);
         a.omega = 0.0;
+        a.rows = apply_rows;
         a.partials = partials + static_cast<size_t>(poff[k]) * MAX_PARTIALS;
     }
-    HIPCHK(launch_apply_vin(blocks.data(), static_cast<int>(blocks.size()), edge, rr, vv, X, PQ, out, partials + static_cast<size_t>(poff_edge) * MAX_PARTIALS,
-                            scalars_for(), stream));
-    reduce_update(nwg_apply, STEP_SS_TSTT);
+    VirtualIn V;
+    V.kind = kind;
+    V.in = in;
+    V.in2 = in2;
+    V.in3 = in3;
+    V.aux = kind == VK_P ? r_hat : nullptr;
+    V.pout = pout;
+    HIPCHK(launch_apply_virtual(blocks.data(), static_cast<int>(blocks.size()), edge, V, X, PQ, out, partials + static_cast<size_t>(poff_edge) * MAX_PARTIALS,
+                                scalars_for(), stream));
+    reduce_update(nwg_apply, kind == VK_P ? STEP_SIGMA : STEP_SS_TSTT);
 }
 
 void Smoother::white_launch(int update) {
@@ -767,6 +811,41 @@ void Smoother::precondition(const double2* in, double2* out) {
     }
 }
 
+// Convergence poll of the inner solve: 0 = keep iterating, 1 = both components converged, 2 = a component broke down.
+// A small mesh runs 8 iterations in ~250 us and a blocking read of the scalar block costs ~30 us of idle device: there the copy
+// is only ENQUEUED (after iteration `it`), the next iterations follow it into the queue, and the copy made at the PREVIOUS poll
+// is the one examined.  Iterations past the end are harmless by construction: a finished component has alpha = omega = beta = 0
+// (scalar_update_body), so its U and r no longer move and `done` never reverts.  `poll_iters` = the iteration count of the poll
+// that saw the end (what a blocking poll would have reported).
+int Smoother::poll_done(uint64_t it, bool final) {
+    auto verdict = [&](const KrylovScalars* h) { return (h->done[0] && h->done[1]) ? ((h->done[0] == 1 && h->done[1] == 1) ? 1 : 2) : 0; };
+    flush_pending();
+    if (!pipelined_poll) {
+        HIPCHK(hipMemcpyAsync(h_S, S, sizeof(KrylovScalars), hipMemcpyDeviceToHost, stream));
+        sync();
+        poll_iters = it;
+        return verdict(h_S);
+    }
+    int v = 0;
+    const int cur = poll_slot, prev = poll_slot ^ 1;
+    HIPCHK(hipMemcpyAsync(h_poll[cur], S, sizeof(KrylovScalars), hipMemcpyDeviceToHost, stream));
+    HIPCHK(hipEventRecord(ev_poll[cur], stream));
+    if (poll_open) {
+        HIPCHK(hipEventSynchronize(ev_poll[prev]));
+        v = verdict(h_poll[prev]);
+        if (v) poll_iters = poll_it[prev];
+    }
+    if (!v && final) {
+        HIPCHK(hipEventSynchronize(ev_poll[cur]));
+        v = verdict(h_poll[cur]);
+        poll_iters = it;
+    }
+    poll_it[cur] = it;
+    poll_open = true;
+    poll_slot = prev;
+    return v;
+}
+
 // ------------------------------------------------------------------ Picard + BiCGStab
 // One outer iteration: returns 1 if the inner solve did not converge.
 int Smoother::picard_bicgstab(tm_stats& st) {
@@ -785,6 +864,7 @@ int Smoother::picard_bicgstab(tm_stats& st) {
     int restarts = 0;
     uint64_t it_total = 0;
     bool converged = false;
+    poll_iters = 0;
     while (true) {
         // r = D^-1 (b - A U) ; r_hat = r ; p = v = 0
         apply(U, r, MODE_RESID, DOT_OUT2, nullptr, X, 0.0, STEP_INIT);
@@ -804,28 +884,35 @@ int Smoother::picard_bicgstab(tm_stats& st) {
             }
         }
         bool breakdown = false;
+        poll_open = false;
         while (it_total < opt.max_inner) {
-            HIPCHK(launch_p_update(scalars_for(), r, p, v, n_owned, stream));
-            if (use_mg) {   // right preconditioning (BiCGStab.zig:314-316, 340-342 with M = one V-cycle)
-                precondition(p, p_hat);
-                apply(p_hat, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0, STEP_SIGMA);
+            if (fuse_p) {
+                // p = r + beta (p - omega v) is formed as the rows enter the first apply's window and stored from there; the new p
+                // and v go to the alternate arrays (the halos of neighbouring workgroups still read the old ones)
+                apply_virtual(VK_P, r, p, v, p_alt, v_alt);
+                std::swap(p, p_alt);
+                std::swap(v, v_alt);
             } else {
-                apply(p, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0, STEP_SIGMA);
+                HIPCHK(launch_p_update(scalars_for(), r, p, v, n_owned, stream));
+                if (use_mg) {   // right preconditioning (BiCGStab.zig:314-316, 340-342 with M = one V-cycle)
+                    precondition(p, p_hat);
+                    apply(p_hat, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0, STEP_SIGMA);
+                } else {
+                    apply(p, v, MODE_SCALED, DOT_AUX, r_hat, X, 0.0, STEP_SIGMA);
+                }
             }
             if (fuse_s) {
                 // s = r - alpha v is never stored: the second apply forms it as the rows enter its window (interior rows and
                 // perimeter rows), with ||s||^2 beside t.s and t.t in one reduction; k_xr_update_vs forms it again
-                apply_vin(r, v, t);
+                apply_virtual(VK_S, r, v, nullptr, nullptr, t);
                 HIPCHK(launch_xr_update_vs(scalars_for(), U, p, v, t, r, r_hat, n_owned, partials, stream));
                 reduce_update(nwg_vec, STEP_RHO);
                 st.operator_sweeps += 2;
                 it_total += 1;
                 if (it_total % opt.check_every == 0 || it_total == opt.max_inner) {
-                    flush_pending();
-                    HIPCHK(hipMemcpyAsync(h_S, S, sizeof(KrylovScalars), hipMemcpyDeviceToHost, stream));
-                    sync();
-                    if (h_S->done[0] && h_S->done[1]) {
-                        converged = h_S->done[0] == 1 && h_S->done[1] == 1;
+                    const int verdict = poll_done(it_total, it_total == opt.max_inner);
+                    if (verdict) {
+                        converged = verdict == 1;
                         breakdown = !converged;
                         break;
                     }
@@ -845,11 +932,9 @@ int Smoother::picard_bicgstab(tm_stats& st) {
             st.operator_sweeps += 2;
             it_total += 1;
             if (it_total % opt.check_every == 0 || it_total == opt.max_inner) {
-                flush_pending();
-                HIPCHK(hipMemcpyAsync(h_S, S, sizeof(KrylovScalars), hipMemcpyDeviceToHost, stream));
-                sync();
-                if (h_S->done[0] && h_S->done[1]) {
-                    converged = h_S->done[0] == 1 && h_S->done[1] == 1;
+                const int verdict = poll_done(it_total, it_total == opt.max_inner);
+                if (verdict) {
+                    converged = verdict == 1;
                     breakdown = !converged;
                     break;
                 }
@@ -858,7 +943,7 @@ int Smoother::picard_bicgstab(tm_stats& st) {
         if (converged || !breakdown || restarts >= 8 || it_total >= opt.max_inner) break;
         restarts += 1;   // breakdown (rho or omega vanished): restart from the current iterate
     }
-    st.inner_iterations += it_total;
+    st.inner_iterations += (converged && poll_iters) ? poll_iters : it_total;
     flush_pending();
 
     // residual + copy-back (smooth.zig:112-153); X becomes the new frozen field

@@ -91,6 +91,13 @@ struct Smoother {
     double* red = nullptr;
     KrylovScalars* S = nullptr;
     KrylovScalars* h_S = nullptr;   // pinned
+    // pipelined convergence poll (poll_done): two pinned copies of the scalar block in flight alternately
+    bool pipelined_poll = false, poll_open = false;
+    KrylovScalars* h_poll[2] = {nullptr, nullptr};
+    hipEvent_t ev_poll[2] = {nullptr, nullptr};
+    uint64_t poll_it[2] = {0, 0}, poll_iters = 0;
+    int poll_slot = 0;
+    int poll_done(uint64_t it, bool final);
     double* h_red = nullptr;        // pinned
     std::vector<int> poff;          // partial-row offset of each owned block's K2 launch
     int poff_edge = 0, nwg_apply = 0, nwg_vec = 0;
@@ -147,8 +154,11 @@ struct Smoother {
     void reduce(int nwg);   // partials -> red (+ all-reduce)
     void reduce_update(int nwg, int step, double rtol = 0.0, double atol = 0.0);   // reduce + Krylov scalar update
     // lazy scalar steps (small single-process meshes): see LazyScalars in tm_kernels.h
-    bool fuse_s = false;            // k_apply_vin / k_xr_update_vs instead of k_s_update + apply + k_xr_update
-    void apply_vin(const double2* r, const double2* v, double2* out);
+    int apply_rows = 0;             // K2 rows per chunk of this handle (0 = per-block rule)
+    bool fuse_s = false;            // k_apply_vk<VK_S> / k_xr_update_vs instead of k_s_update + apply + k_xr_update
+    bool fuse_p = false;            // k_apply_vk<VK_P> instead of k_p_update + apply; p and v alternate with p_alt, v_alt
+    double2 *p_alt = nullptr, *v_alt = nullptr;
+    void apply_virtual(int kind, const double2* in, const double2* in2, const double2* in3, double2* pout, double2* out);
     bool lazy = false;
     double* part_buf[3] = {nullptr, nullptr, nullptr};
     int part_rot = 0;
