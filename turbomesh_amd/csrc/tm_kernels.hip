@@ -802,15 +802,15 @@ void tune_fuse_rows(int rows) { g_fuse_rows = rows > 0 ? rows : 0; }
 
 // Rows per chunk of K2.  A block that cannot fill the device is bound by the chain of dependent row-group loads in each wave
 // (a round trip per 3 rows), not by bandwidth: it gets the shortest chunks (multiples of the 3-row load group) that keep the launch
-// within one round of workgroups (T106, 8 blocks of 10^2..10^4 nodes: 42.5 -> 29.7 us per BiCGStab iteration with 3 rows instead
-// of 18).  `rows` > 0: the caller's choice (a handle that looked at all of its blocks, Smoother::create).
+// within 512 workgroups = two per CU (T106, 8 blocks of 10^2..10^4 nodes: 42.5 -> 29.7 us per BiCGStab iteration with 3 rows
+// instead of 18; a 1024^2 block, 9 rows: 88 -> 81 us; with 1024 workgroups the lazy scalar steps no longer apply: 95 us).  `rows` > 0: the caller's choice (a handle that looked at all of its blocks, Smoother::create).
 static inline int rows_per_chunk(int ni, int nj, int rows = 0) {
     const int interior = ni - 2;
     int RI = rows > 0 ? rows : g_rows_per_chunk;
     if (rows <= 0 && !g_rows_forced) {
         const int nSG = (nj + 255) / 256;
         int r = 3;
-        while (r < RI && nSG * ((interior + r - 1) / r) > 256) r += 3;
+        while (r < RI && nSG * ((interior + r - 1) / r) > 512) r += 3;
         RI = std::min(RI, r);
     }
     if (RI > interior) RI = interior;

@@ -407,12 +407,12 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     }
 
     // ---- reductions
-    // K2 chunk length for this handle: several small blocks in one launch -- the shortest chunks (multiples of the 3-row load
-    // group) that keep interior + perimeter workgroups within what the lazy scalar steps allow (512 partial rows); a single block
-    // and large meshes: the per-block rule of tm_kernels.hip (apply_rows = 0)
+    // K2 chunk length for this handle: all owned blocks go into one launch -- the shortest chunks (multiples of the 3-row load
+    // group) that keep interior + perimeter workgroups within what the lazy scalar steps allow (512 partial rows); large meshes:
+    // the per-block rule of tm_kernels.hip (apply_rows = 0)
     const int edge_wg = (opt.inner == TM_INNER_RELAX ? edge_nf.nwg : edge.nwg);   // a relax handle only ever launches the non-fixed rows
     apply_rows = 0;
-    if (lp.owned_blocks.size() > 1) {
+    {
         for (int r = 3; r < 18 && !apply_rows; r += 3) {
             int total = edge_wg;
             for (int64_t b : lp.owned_blocks) total += apply_block_nwg(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), r);
