@@ -72,6 +72,63 @@ def test_config1_t106_json_as_written_on_the_cpu_oracle():
     assert st.residual_history[-1] < 1e-4 * st.residual_history[0] and np.isfinite(om.flat()).all()
 
 
+def _t106_block0(tfi):
+    """BASELINE configs[0] read literally -- "examples/T106 single 2D block, linear TFI + 100 elliptic iters" (SURVEY 8d config 1,
+    variant (ii)): block 0 of the O4H blocking (221 x 41, the O-grid half around the suction side) on its own, all four sides
+    fixed, Laplace control function."""
+    from turbomesh_amd.discrete import Mesh
+
+    _, full = load("T106", tfi)
+    m = Mesh()
+    m.addBlock("blade_up", full.blocks[0])
+    return m
+
+
+def test_config1_single_block_100_iterations_on_the_cpu_oracle():
+    # 100 Picard iterations on the CPU oracle, three inner solvers against the exact-solve iteration (= the reference with UMFPACK)
+    mesh = _t106_block0(oracle_tfi)
+    assert mesh.blocks[0].points.data.shape == (221, 41, 2)
+    exact = OracleMesh(_t106_block0(oracle_tfi))
+    hist, _ = oracle.picard_exact(exact, 100)
+    assert hist[-1] < 1e-12 * hist[0]                      # the Picard iteration has converged: (sum dx^2 + sum dy^2)^2
+
+    def run(solver_tag, precond):
+        om = OracleMesh(_t106_block0(oracle_tfi))
+        st = oracle.smooth_mesh(om, 100, solver=solver_tag, preconditioner=precond)
+        assert st.outer_iterations == 100 and st.not_converged == 0
+        return st, float(np.sqrt(np.mean((om.flat() - exact.flat()) ** 2)))
+
+    # (1) the scale-aware criterion this build solves with (DESIGN.md section 5): the exact fixed point
+    st, rms = run(oracle.SOLVER_SCALED_BICGSTAB, oracle.PRECOND_DIAGONAL)
+    assert rms <= 1e-10, rms
+    # (2) the reference's own settings, restated faithfully (SURVEY H2): the stop test max(1e-8, 1e-6 ||b||) acts on the UNSCALED
+    # residual, whose interior rows are O(h^2) -- GMRES + ILU(0) (the solver of T106.json) stops iterating after the first few
+    # outer iterations and stalls ~1e-6 RMS short of the fixed point; BiCGStab + diagonal returns before its first iteration
+    st, rms = run(oracle.SOLVER_GMRES, oracle.PRECOND_ILU0)
+    assert 1e-10 < rms < 5e-6 and st.inner_iterations < 100, (rms, st.inner_iterations)
+    st, rms = run(oracle.SOLVER_BICGSTAB, oracle.PRECOND_DIAGONAL)
+    assert st.inner_iterations == 0 and not st.residual_history.any() and rms > 1e-5
+
+
+@pytest.mark.gpu
+def test_gpu_config1_single_block_100_iterations():
+    # the same job on the GPU through smooth.mesh (one call, 100 Picard iterations): CONVERGED coordinates within 1e-10 RMS of
+    # the CPU oracle's (north_star), TFI seed bit-identical
+    mesh = _t106_block0(None)
+    ref = _t106_block0(oracle_tfi)
+    assert mesh.blocks[0].points.data.tobytes() == ref.blocks[0].points.data.tobytes()
+    exact = OracleMesh(ref)
+    hist, _ = oracle.picard_exact(exact, 100)
+    x0 = mesh.blocks[0].points.data.copy()
+    st = smooth.mesh(mesh, 100, solver.Option.hip(rtol=1e-13, max_inner=20000))
+    assert st["outer_iterations"] == 100 and st["not_converged"] == 0
+    rms = float(np.sqrt(np.mean((mesh_flat(mesh) - exact.flat()) ** 2)))
+    moved = float(np.sqrt(np.mean((mesh_flat(mesh) - x0.reshape(-1, 2)) ** 2)))
+    assert rms <= 1e-10, rms
+    assert moved > 1e-4                                    # the smoothing did something: the seed is far from the fixed point
+    assert st["last_residual"] <= 1e-12 * hist[0]
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("name", ["T106", "LS89"])
 def test_gpu_o4h_tfi_and_smoothing(name):
