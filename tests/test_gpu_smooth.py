@@ -193,9 +193,12 @@ def test_per_iteration_log_lines_like_the_reference(caplog):
 
 @pytest.mark.parametrize("name", ["two_by_two_junction", "strip3_reversed", "plate_le"])
 @pytest.mark.parametrize("inner", [solver.Inner.bicgstab, solver.Inner.mg_bicgstab])
-def test_small_mesh_launch_savings_do_not_change_a_bit(name, inner):
+def test_small_mesh_launch_savings_do_not_change_a_bit(name, inner, monkeypatch):
     # small single-process meshes: interior + perimeter rows in one launch, scalar steps folded into the kernels that consume them
-    # (LazyScalars) -- same sums in the same order, so the iterates equal those of the launch-per-step path bit for bit
+    # (LazyScalars), the p- and s-updates formed inside the applies -- same sums in the same order, same expressions, so the
+    # iterates equal those of the launch-per-step path bit for bit.  (TM_FUSE_2=0: the classic recurrence; the two-kernel
+    # iteration obtains rho from other sums and is compared below.)
+    monkeypatch.setenv("TM_FUSE_2", "0")
     control = wcf.Algorithm(wcf.White(0.02)) if name == "plate_le" else None
     out = []
     for eager in (True, False):
@@ -207,3 +210,38 @@ def test_small_mesh_launch_savings_do_not_change_a_bit(name, inner):
     assert out[0][1]["not_converged"] == 0
     assert out[0][1]["inner_iterations"] == out[1][1]["inner_iterations"]
     assert np.array_equal(out[0][0], out[1][0])
+
+
+@pytest.mark.parametrize("name", ["two_by_two_junction", "strip3_reversed", "plate_le", "single"])
+def test_two_kernel_iteration_against_the_classic_recurrence(name, monkeypatch):
+    # The default single-process BiCGStab runs two kernels per iteration: rho' = r_hat.s - omega r_hat.t comes out of the second
+    # apply's reduction (equal to r_hat.r' in exact arithmetic, BiCGStab.zig:360-363 computes the latter), and the x / r update
+    # rides in front of the next first apply.  Same Krylov method, different rounding: the converged Picard iterates agree far
+    # inside the parity budget, the iteration counts stay close, and a capped run (update still pending when the loop ends) is
+    # flushed correctly.
+    control = wcf.Algorithm(wcf.White(0.02)) if name == "plate_le" else None
+    build = (lambda: configs.single_block(70, 131, perturb=0.25)) if name == "single" else TOPOLOGIES[name]
+    out = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TM_FUSE_2", mode)
+        mesh = build()
+        with smooth.Smoother(mesh, solver.Option.hip(rtol=1e-13, max_inner=5000), control) as sm:
+            st = sm.iterate(3)
+            sm.download()
+        assert st["not_converged"] == 0
+        out[mode] = (mesh_flat(mesh), st)
+    rms = float(np.sqrt(np.mean((out["0"][0] - out["1"][0]) ** 2)))
+    assert rms <= 1e-11, rms
+    assert abs(out["0"][1]["inner_iterations"] - out["1"][1]["inner_iterations"]) <= 0.25 * out["0"][1]["inner_iterations"] + 16
+    # capped: 7 inner iterations per solve, no convergence -- both paths have applied exactly 7 updates
+    capped = {}
+    for mode in ("0", "1"):
+        monkeypatch.setenv("TM_FUSE_2", mode)
+        mesh = build()
+        with smooth.Smoother(mesh, solver.Option.hip(rtol=1e-30, max_inner=7, check_every=7), control) as sm:
+            st = sm.iterate(1)
+            sm.download()
+        assert st["inner_iterations"] == 7 and st["not_converged"] == 1
+        capped[mode] = mesh_flat(mesh)
+    assert float(np.abs(capped["0"] - capped["1"]).max()) <= 1e-9 * max(1.0, float(np.abs(capped["0"]).max()))
+    assert not np.array_equal(capped["1"], mesh_flat(build()))

@@ -154,9 +154,11 @@ def test_multi_rank_equals_single_rank(name, builder, owner):
     smooth.mesh(ref, 3, opt)
     got = _run_ranks(builder, owner, opt, 3)
     rms = float(np.sqrt(np.mean((mesh_flat(got) - mesh_flat(ref)) ** 2)))
-    # both runs solve the same frozen systems to rtol 1e-13 with different reduction orders; each is within 1e-10 RMS of the
-    # exact iterate (tests/test_gpu_smooth.py), so they may differ from each other by up to twice that
-    assert rms <= 2e-10, (name, rms)
+    # both runs solve the same frozen systems to rtol 1e-13 with different reduction orders (and the single-rank handle with the
+    # two-kernel recurrence); the distance to the exact iterate is (condition number) x rtol: <= 1e-10 RMS on the small cases
+    # (tests/test_gpu_smooth.py), 1.4e-10 .. 1.6e-10 on the 2 x 200 x 700 strip (tools/dev/parity_two_kernel.py) -- and the two
+    # runs may differ from each other by up to twice that
+    assert rms <= (4e-10 if name == "strip2_big" else 2e-10), (name, rms)
 
 
 def test_multi_rank_multigrid_preconditioner():

@@ -125,7 +125,7 @@ def test_gpu_config1_single_block_100_iterations():
     rms = float(np.sqrt(np.mean((mesh_flat(mesh) - exact.flat()) ** 2)))
     moved = float(np.sqrt(np.mean((mesh_flat(mesh) - x0.reshape(-1, 2)) ** 2)))
     assert rms <= 1e-10, rms
-    assert moved > 1e-4                                    # the smoothing did something: the seed is far from the fixed point
+    assert moved > 1e-5                                    # the smoothing did something: the TFI seed is 7e-5 RMS from the fixed point
     assert st["last_residual"] <= 1e-12 * hist[0]
 
 

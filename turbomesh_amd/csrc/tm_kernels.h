@@ -33,9 +33,10 @@ enum DotMode : int {
     DOT_OUT2 = 3,   // [out.out]_x, [out.out]_y                       (||r||^2)
     DOT_DELTA = 4,  // [(out-in)^2]_x, [(out-in)^2]_y                 (relax: sum dx^2, dy^2)
     DOT_AUX2 = 5,   // [aux.out]_x, [aux.out]_y, [out.out]_x, [out.out]_y (t.s, t.t when the operator acted on a preconditioned vector)
-    DOT_IN_SS = 6   // DOT_IN + [in.in]_x, [in.in]_y   (t.s, t.t, ||s||^2: the second apply of an iteration acting on s = r - alpha v formed on the fly)
+    DOT_IN_SS = 6,  // DOT_IN + [in.in]_x, [in.in]_y   (t.s, t.t, ||s||^2: the second apply of an iteration acting on s = r - alpha v formed on the fly)
+    DOT_B2 = 7      // DOT_IN + [aux.in]_x,y + [aux.out]_x,y   (t.s, t.t, r_hat.s, r_hat.t: the two-kernel iteration, STEP_B2)
 };
-constexpr int MAX_PARTIALS = 6;
+constexpr int MAX_PARTIALS = 8;
 struct KrylovScalars;
 struct LazyScalars;
 
@@ -43,7 +44,10 @@ struct ApplyBlock {
     // virtual-input kernels (launch_apply_virtual): the operator acts on a vector formed on the fly from in, in2, in3
     const double2* in2 = nullptr;
     const double2* in3 = nullptr;
-    double2* pout = nullptr;        // VK_P: where the formed vector is stored (owned rows)
+    double2* pout = nullptr;        // VK_P, VK_R: where the formed vector is stored (owned rows)
+    const double2* in4 = nullptr;   // VK_R: p
+    double2* rout = nullptr;        // VK_R: the updated residual (owned rows)
+    double2* uio = nullptr;         // VK_R: the solution vector, updated in place (owned rows)
     int rows = 0;                   // rows per chunk; 0 = the per-block rule (rows_per_chunk, tm_kernels.hip)
     const double2* in;    // vector the operator acts on, pointing at the block's node (0,0)
     const double2* xk;    // frozen coordinates the coefficients are built from (== in for field mode)
@@ -146,11 +150,19 @@ hipError_t launch_apply_edge_blocks(const ApplyBlock* blocks, int n, int mode, i
 // in = r; (in2, in3) = (v, -) or (p, v).  Rank-local vectors; blocks[k].in/in2/in3/pout point at the block's node (0,0).
 // Interior rows of all blocks (one launch per group of APPLY_BATCH_MAX) and the perimeter rows; the scalars come from `scal`
 // (pending steps applied by the first kernel that runs).
-constexpr int VK_NONE = 0, VK_S = 1, VK_P = 2;
+//   kind 3 (r):  the whole vector part of an iteration in front of its first apply (two-kernel iteration):
+//                s = in - alpha in2, r' = s - omega in3, p' = r' + beta (in4 - omega in2), u += alpha in4 + omega s;
+//                out = D^-1 A p'; r', p' stored to rout, pout (arrays other than in, in4), u in place; partial sums r_hat . out and
+//                ||r'||^2 (STEP_A2).  in = r, in2 = v, in3 = t, in4 = p, aux = r_hat.
+//   kind 4 (s2): kind 1 with the partial sums t.s, t.t, r_hat.s, r_hat.t (DOT_B2, STEP_B2), aux = r_hat
+constexpr int VK_NONE = 0, VK_S = 1, VK_P = 2, VK_R = 3, VK_S2 = 4;
 struct VirtualIn {
     int kind;
     const double2 *in, *in2, *in3, *aux;
     double2* pout;
+    const double2* in4 = nullptr;
+    double2* rout = nullptr;
+    double2* uio = nullptr;
 };
 hipError_t launch_apply_virtual(const ApplyBlock* blocks, int n, const EdgeRowsDev& e, const VirtualIn& V, const double2* xk, const double2* pq, double2* out,
                                 double* edge_partials, const LazyScalars& scal, hipStream_t stream);
@@ -181,7 +193,12 @@ struct KrylovScalars {   // one per smoother, lives in device memory; index = co
 constexpr int VEC_BLOCK = 256;
 int vec_nwg(int64_t n);
 // step ids for launch_scalar_update: consume red[], update KrylovScalars
-enum ScalarStep : int { STEP_INIT = 0, STEP_SIGMA = 1, STEP_SS = 2, STEP_TSTT = 3, STEP_RHO = 4, STEP_TOL = 5, STEP_SS_TSTT = 6 };
+enum ScalarStep : int { STEP_INIT = 0, STEP_SIGMA = 1, STEP_SS = 2, STEP_TSTT = 3, STEP_RHO = 4, STEP_TOL = 5, STEP_SS_TSTT = 6, STEP_INIT2 = 7, STEP_A2 = 8, STEP_B2 = 9 };
+// Two-kernel iteration (VK_R / VK_S2): rho comes from the second apply's reduction, rho' = r_hat.s - omega r_hat.t (= r_hat.r'), so
+// the x / r update needs no reduction of its own and rides in front of the next first apply:
+//   STEP_INIT2: STEP_INIT with alpha = omega = beta = 0 (nothing pending; p' = r)
+//   STEP_A2:    red[0..1] = r_hat.v', red[2..3] = ||r'||^2 -> convergence / breakdown of the update just applied, alpha = rho / sigma
+//   STEP_B2:    red[0..1] = t.s, red[2..3] = t.t, red[4..5] = r_hat.s, red[6..7] = r_hat.t -> omega, rho, beta
 // STEP_SS_TSTT: red[4..5] = ||s||^2, red[0..1] = t.s, red[2..3] = t.t -- STEP_SS then STEP_TSTT from one reduction (DOT_IN_SS)
 // STEP_TOL: red[0..1] = ||D^-1 b||^2 -> tol2 = max(atol, rtol*||D^-1 b||)^2
 hipError_t launch_scalar_update(KrylovScalars* S, const double* red, int step, hipStream_t stream, double rtol = 0.0, double atol = 0.0);

@@ -134,6 +134,15 @@ __device__ __forceinline__ void accumulate(double (&acc)[MAX_PARTIALS], double2 
         acc[3] += out.y * out.y;
         acc[4] += in_self.x * in_self.x;
         acc[5] += in_self.y * in_self.y;
+    } else if (DOT == DOT_B2) {
+        acc[0] += in_self.x * out.x;
+        acc[1] += in_self.y * out.y;
+        acc[2] += out.x * out.x;
+        acc[3] += out.y * out.y;
+        acc[4] += aux.x * in_self.x;
+        acc[5] += aux.y * in_self.y;
+        acc[6] += aux.x * out.x;
+        acc[7] += aux.y * out.y;
     } else if (DOT == DOT_OUT2) {
         acc[0] += out.x * out.x;
         acc[1] += out.y * out.y;
@@ -243,9 +252,20 @@ __device__ __forceinline__ void store_nt(double2* dst, double2 v) {
 
 // The vector a Krylov update would have stored, formed where it is consumed (the expressions of k_s_update / k_p_update; the
 // library is built with -ffp-contract=off, so they give the same bits wherever they are formed)
+// VK_R (x = r, y = v, z = t, w = p; va = alpha, vb = omega, vc = beta): the pending x / r update and the p-update in one go
+struct VirtualR {
+    double2 s, rn, pn;   // s = r - alpha v, r' = s - omega t, p' = r' + beta (p - omega v)
+};
+__device__ __forceinline__ VirtualR virtual_r(double2 x, double2 y, double2 z, double2 w, double2 va, double2 vb, double2 vc) {
+    VirtualR o;
+    o.s = make_double2(x.x - va.x * y.x, x.y - va.y * y.y);
+    o.rn = make_double2(o.s.x - vb.x * z.x, o.s.y - vb.y * z.y);
+    o.pn = make_double2(o.rn.x + vc.x * (w.x - vb.x * y.x), o.rn.y + vc.y * (w.y - vb.y * y.y));
+    return o;
+}
 template <int VK>
 __device__ __forceinline__ double2 virtual_vec(double2 x, double2 y, double2 z, double2 va, double2 vb) {
-    if (VK == VK_S) return make_double2(x.x - va.x * y.x, x.y - va.y * y.y);   // s = r - alpha v (BiCGStab.zig:325-327)
+    if (VK == VK_S || VK == VK_S2) return make_double2(x.x - va.x * y.x, x.y - va.y * y.y);   // s = r - alpha v (BiCGStab.zig:325-327)
     if (VK == VK_P) return make_double2(x.x + va.x * (y.x - vb.x * z.x), x.y + va.y * (y.y - vb.y * z.y));   // p = r + beta (p - omega v) (BiCGStab.zig:310-312)
     return x;
 }
@@ -254,9 +274,11 @@ __device__ __forceinline__ double2 virtual_vec(double2 x, double2 y, double2 z, 
 // VK (virtual input vector, formed as the rows are taken into the window; va, vb component-wise):
 //   VK_S: in - va * in2                (s = r - alpha v, never stored)
 //   VK_P: in + va * (in2 - vb * in3)   (p = r + beta (p - omega v), stored to a.pout for the owned rows)
+//   VK_R: virtual_r(in, in2, in3, in4) (va, vb, vc = alpha, omega, beta): r', p' and the solution update stored for the owned rows
+//         as each row ENTERS the window (a row enters once per workgroup; the chunk's two halo rows belong to the neighbours)
 template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool NT, int VK = VK_NONE>
 __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG, int nRC, int bid, double2 va = make_double2(0.0, 0.0),
-                                           double2 vb = make_double2(0.0, 0.0)) {
+                                           double2 vb = make_double2(0.0, 0.0), double2 vc = make_double2(0.0, 0.0)) {
     static_assert(U % 3 == 0, "the 3-row window rotates by renaming: the row group must be a multiple of 3");
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -292,11 +314,43 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
         double2 Wc[3], We[3], Wh[3];
         double2 Xc[3], Xdet = make_double2(0.0, 0.0);   // frozen coordinates when they are a different array; Xdet of the centre row
         auto comb = [&](double2 x, double2 y, double2 z) { return virtual_vec<VK>(x, y, z, va, vb); };
+        // VK_R: centre value of an entering row -> p'; for an owned row the node's r', p', u are stored and ||r'||^2 accumulated
+        auto enter = [&](int row, bool owned_row, double2 x, double2 y, double2 z, double2 w, double2 u0) {
+            const VirtualR q = virtual_r(x, y, z, w, va, vb, vc);
+            if (owned_row && valid_col) {
+                const size_t at = static_cast<size_t>(row) * nj + j;
+                double2 un = u0;
+                un.x += va.x * w.x;   // BiCGStab.zig:329-331 (x += alpha * p_hat), k_xr_update_vs's expressions
+                un.y += va.y * w.y;
+                un.x += vb.x * q.s.x;   // BiCGStab.zig:352-354 (x += omega * s_hat)
+                un.y += vb.y * q.s.y;
+                store_nt(a.uio + at, un);
+                store_nt(a.rout + at, q.rn);
+                store_nt(a.pout + at, q.pn);
+                acc[2] += q.rn.x * q.rn.x;
+                acc[3] += q.rn.y * q.rn.y;
+            }
+            return q.pn;
+        };
+        auto halo_r = [&](double2 x, double2 y, double2 z, double2 w) { return virtual_r(x, y, z, w, va, vb, vc).pn; };
         {
             double2 h0, h1;
             load_row(a.in, i0 - 1, Wc[0], h0);
             load_row(a.in, i0, Wc[1], h1);
-            if (VK != VK_NONE) {
+            if (VK == VK_R) {
+                double2 q0, g0, q1, g1, z0, y0, z1, y1, w0, k0, w1, k1;
+                load_row(a.in2, i0 - 1, q0, g0);
+                load_row(a.in2, i0, q1, g1);
+                load_row(a.in3, i0 - 1, z0, y0);
+                load_row(a.in3, i0, z1, y1);
+                load_row(a.in4, i0 - 1, w0, k0);
+                load_row(a.in4, i0, w1, k1);
+                const double2 u1 = a.uio[static_cast<size_t>(i0) * nj + jc];
+                h0 = halo_r(h0, g0, y0, k0);
+                h1 = halo_r(h1, g1, y1, k1);
+                Wc[0] = enter(i0 - 1, false, Wc[0], q0, z0, w0, u1);
+                Wc[1] = enter(i0, true, Wc[1], q1, z1, w1, u1);
+            } else if (VK != VK_NONE) {
                 double2 q0, g0, q1, g1, z0 = make_double2(0.0, 0.0), y0 = z0, z1 = z0, y1 = z0;
                 load_row(a.in2, i0 - 1, q0, g0);
                 load_row(a.in2, i0, q1, g1);
@@ -323,7 +377,8 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
         }
 
         struct Group {
-            double2 pc[U], ph[U], xpc[U], xph[U], pqv[U], auxv[U], qc[VK != VK_NONE ? U : 1], qh[VK != VK_NONE ? U : 1], zc[VK == VK_P ? U : 1], zh[VK == VK_P ? U : 1];
+            double2 pc[U], ph[U], xpc[U], xph[U], pqv[U], auxv[U], qc[VK != VK_NONE ? U : 1], qh[VK != VK_NONE ? U : 1];
+            double2 zc[(VK == VK_P || VK == VK_R) ? U : 1], zh[(VK == VK_P || VK == VK_R) ? U : 1], wc[VK == VK_R ? U : 1], wh[VK == VK_R ? U : 1], uc[VK == VK_R ? U : 1];
         };
         auto load_group = [&](int ib, Group& g) {   // rows ib+1 .. ib+U of the vector (and of xk), pq/aux of rows ib .. ib+U-1
 #pragma unroll
@@ -335,11 +390,15 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
                 } else
                     load_row(a.in, prow, g.pc[u], g.ph[u]);
                 if (VK != VK_NONE) load_row(a.in2, prow, g.qc[u], g.qh[u]);
-                if (VK == VK_P) load_row(a.in3, prow, g.zc[u], g.zh[u]);
+                if (VK == VK_P || VK == VK_R) load_row(a.in3, prow, g.zc[u], g.zh[u]);
+                if (VK == VK_R) {
+                    load_row(a.in4, prow, g.wc[u], g.wh[u]);
+                    g.uc[u] = a.uio[static_cast<size_t>(prow) * nj + jc];
+                }
                 if (!FIELD) load_row(a.xk, prow, g.xpc[u], g.xph[u]);
                 const size_t cur = static_cast<size_t>(min(ib + u, ni - 2)) * nj + jc;
                 if (HAS_PQ) g.pqv[u] = a.pq[cur];
-                if (DOT == DOT_AUX || DOT == DOT_AUX2 || MODE == MODE_MG_RESID || MODE == MODE_MG_SMOOTH) g.auxv[u] = a.aux[cur];
+                if (DOT == DOT_AUX || DOT == DOT_AUX2 || DOT == DOT_B2 || MODE == MODE_MG_RESID || MODE == MODE_MG_SMOOTH) g.auxv[u] = a.aux[cur];
             }
         };
         // PRED = false: full wave and full row group -> no exec masking around the arithmetic and the store
@@ -349,8 +408,14 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
             for (int u = 0; u < U; ++u) {
                 const int M = u % 3, C = (u + 1) % 3, P3 = (u + 2) % 3;   // window slots of rows i-1, i, i+1
                 const int row = ib + u;
-                const double2 nc = VK != VK_NONE ? comb(g.pc[u], g.qc[u], g.zc[VK == VK_P ? u : 0]) : g.pc[u];
-                const double2 nh = VK != VK_NONE ? comb(g.ph[u], g.qh[u], g.zh[VK == VK_P ? u : 0]) : g.ph[u];
+                double2 nc, nh;
+                if (VK == VK_R) {
+                    nc = enter(row + 1, row + 1 < i1, g.pc[u], g.qc[u], g.zc[VK == VK_R ? u : 0], g.wc[VK == VK_R ? u : 0], g.uc[VK == VK_R ? u : 0]);
+                    nh = halo_r(g.ph[u], g.qh[u], g.zh[VK == VK_R ? u : 0], g.wh[VK == VK_R ? u : 0]);
+                } else {
+                    nc = VK != VK_NONE ? comb(g.pc[u], g.qc[u], g.zc[VK == VK_P ? u : 0]) : g.pc[u];
+                    nh = VK != VK_NONE ? comb(g.ph[u], g.qh[u], g.zh[VK == VK_P ? u : 0]) : g.ph[u];
+                }
                 Wc[P3] = nc;
                 {
                     const double2 l = lane_prev(nh, nc), r = lane_next(nh, nc);
@@ -402,7 +467,7 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
                         *dst = o;
                     }
                     if (VK == VK_P) store_nt(a.pout + static_cast<size_t>(row) * nj + j, Wc[C]);
-                    accumulate<DOT>(acc, Wc[C], o, (DOT == DOT_AUX || DOT == DOT_AUX2) ? g.auxv[u] : ((DOT == DOT_DELTA) ? delta : o));
+                    accumulate<DOT>(acc, Wc[C], o, (DOT == DOT_AUX || DOT == DOT_AUX2 || DOT == DOT_B2) ? g.auxv[u] : ((DOT == DOT_DELTA) ? delta : o));
                 }
                 if (!FIELD) Xdet = sub2(lane_next(g.xph[u], g.xpc[u]), lane_prev(g.xph[u], g.xpc[u]));   // of the next centre row (= row i+1)
             }
@@ -423,7 +488,7 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
         }
     }
     if ((MODE == MODE_DIAG_NOSTORE || MODE == MODE_DIAG_MATH) && acc[0] + acc[1] == 123.456) a.out[0] = make_double2(acc[0], acc[1]);   // keep the arithmetic live
-    if (DOT != DOT_NONE) block_partials<256>(acc, a.partials + static_cast<size_t>(bid) * MAX_PARTIALS);
+    if (DOT != DOT_NONE) block_partials<256, (VK == VK_R ? 4 : dot_columns(DOT))>(acc, a.partials + static_cast<size_t>(bid) * MAX_PARTIALS);
 }
 
 template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool NT>
@@ -696,7 +761,7 @@ __device__ __forceinline__ void relax2_tile(const Relax2Block& a, int RI, int nS
         if (inside) relax2_strip_inside<DOT, U, NT, W1>(a, t, acc);
         else relax2_strip_edge<DOT, U, NT, W1>(a, t, acc);
     }
-    if (DOT != DOT_NONE) block_partials<256>(acc, a.partials + static_cast<size_t>(logical) * MAX_PARTIALS);   // slot = tile id in every launch flavour
+    if (DOT != DOT_NONE) block_partials<256, dot_columns(DOT)>(acc, a.partials + static_cast<size_t>(logical) * MAX_PARTIALS);   // slot = tile id in every launch flavour
 }
 
 template <int DOT, int U, bool NT, bool W1>
@@ -1042,33 +1107,54 @@ __device__ __forceinline__ void edge_row_eval(const EdgeRun& R, const double* __
     o.x = row_out<MODE>(sx, rhs_x, diag_x, w_self.x, om);
     o.y = row_out<MODE>(sy, rhs_y, diag_y, w_self.y, om);
     result = o;
-    accumulate<DOT>(acc, w_self, o, (DOT == DOT_AUX || DOT == DOT_AUX2) ? aux[row] : ((DOT == DOT_DELTA) ? make_double2(o.x - w_self.x, o.y - w_self.y) : o));
+    accumulate<DOT>(acc, w_self, o, (DOT == DOT_AUX || DOT == DOT_AUX2 || DOT == DOT_B2) ? aux[row] : ((DOT == DOT_DELTA) ? make_double2(o.x - w_self.x, o.y - w_self.y) : o));
 }
 
 // Workgroup `wg` of a perimeter-row pass; `tid` = thread within it (threads >= EDGE_BLOCK of a wider block idle).
+// The vectors and scalars of a virtual-input pass (VirtualIn + the scalars read from the scalar block), as the device code sees them
+struct VirtualArgs {
+    const double2 *in2 = nullptr, *in3 = nullptr, *in4 = nullptr;
+    double2 *pout = nullptr, *rout = nullptr, *uio = nullptr;
+    double2 va = make_double2(0.0, 0.0), vb = make_double2(0.0, 0.0), vc = make_double2(0.0, 0.0);
+};
+
 template <int MODE, int DOT, int VK = VK_NONE>
 __device__ __forceinline__ void edge_rows_wg(const EdgeRowsDev& e, int wg, int tid, const double2* __restrict__ in, const double2* __restrict__ xk,
                                              const double2* __restrict__ pq, const double2* __restrict__ aux, double2* __restrict__ out, double omega,
-                                             double (&acc)[MAX_PARTIALS], const double2* __restrict__ in2 = nullptr, double2 va = make_double2(0.0, 0.0),
-                                             const double2* __restrict__ in3 = nullptr, double2 vb = make_double2(0.0, 0.0), double2* __restrict__ pout = nullptr) {
+                                             double (&acc)[MAX_PARTIALS], const VirtualArgs& V = VirtualArgs()) {
     // one workgroup = one stretch of one run: everything read through R is workgroup-uniform (scalar loads)
     const EdgeRun& R = e.runs[__builtin_amdgcn_readfirstlane(e.wg_run[wg])];
     const int k = __builtin_amdgcn_readfirstlane(e.wg_k0[wg]) + tid;
     if (tid < EDGE_BLOCK && k < R.count) {
         double2 o;
         int row;
-        // VK: the vector is formed on the fly (virtual_vec); VK_P also stores it for the row's own node
+        // VK: the vector is formed on the fly (virtual_vec / virtual_r); VK_P and VK_R also store it for the row's own node
         auto vec = [&](int id) {
             const double2 x = in[id];
             if (VK == VK_NONE) return x;
-            const double2 y = in2[id];
-            const double2 z = VK == VK_P ? in3[id] : y;
-            return virtual_vec<VK>(x, y, z, va, vb);
+            const double2 y = V.in2[id];
+            if (VK == VK_R) return virtual_r(x, y, V.in3[id], V.in4[id], V.va, V.vb, V.vc).pn;
+            const double2 z = VK == VK_P ? V.in3[id] : y;
+            return virtual_vec<VK>(x, y, z, V.va, V.vb);
         };
         edge_row_eval<MODE, DOT>(R, e.rhs, k, [&](int, int id) { return vec(id); }, [&](int, int id) { return xk[id]; }, [&](int id) { return vec(id); }, pq, aux,
                                  omega, acc, o, row);
         out[row] = o;
-        if (VK == VK_P) pout[row] = vec(row);
+        if (VK == VK_P) V.pout[row] = vec(row);
+        if (VK == VK_R) {   // the node's own share of the x / r / p updates (k_xr_update_vs's expressions)
+            const double2 w = V.in4[row];
+            const VirtualR q = virtual_r(in[row], V.in2[row], V.in3[row], w, V.va, V.vb, V.vc);
+            double2 un = V.uio[row];
+            un.x += V.va.x * w.x;
+            un.y += V.va.y * w.y;
+            un.x += V.vb.x * q.s.x;
+            un.y += V.vb.y * q.s.y;
+            V.uio[row] = un;
+            V.rout[row] = q.rn;
+            V.pout[row] = q.pn;
+            acc[2] += q.rn.x * q.rn.x;
+            acc[3] += q.rn.y * q.rn.y;
+        }
     }
 }
 
@@ -1079,7 +1165,7 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const d
                                                           double* partials) {
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
     edge_rows_wg<MODE, DOT>(e, blockIdx.x, threadIdx.x, in, xk, pq, aux, out, omega, acc);
-    if (DOT != DOT_NONE) block_partials<EDGE_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
+    if (DOT != DOT_NONE) block_partials<EDGE_BLOCK, dot_columns(DOT)>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
 
 // Interior rows of up to APPLY_BATCH_MAX blocks AND the perimeter rows of the rank in ONE launch (single-process handles: the
@@ -1101,7 +1187,7 @@ __global__ __launch_bounds__(256) void k_apply_edge_batch(ApplyBatch B, int tota
     const int wg = static_cast<int>(blockIdx.x) - total_interior;
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
     edge_rows_wg<MODE, DOT>(e, wg, threadIdx.x, in, xk, pq, aux, out, 0.0, acc);
-    if (DOT != DOT_NONE) block_partials<256>(acc, edge_partials + static_cast<size_t>(wg) * MAX_PARTIALS);   // waves 2, 3 add exact zeros
+    if (DOT != DOT_NONE) block_partials<256, dot_columns(DOT)>(acc, edge_partials + static_cast<size_t>(wg) * MAX_PARTIALS);   // waves 2, 3 add exact zeros
 }
 
 // An apply of a BiCGStab iteration with the vector update in front of it folded in (VirtualIn, tm_kernels.h):
@@ -1113,44 +1199,60 @@ __global__ __launch_bounds__(256) void k_apply_edge_batch(ApplyBatch B, int tota
 // The scalars come from the scalar block, advanced by the pending steps where there are any (LazyScalars).
 // total_interior < 0: interior rows only (the perimeter rows follow in k_edge_rows_vk: large meshes).
 template <int VK>
-__device__ __forceinline__ void virtual_scalars(const KrylovScalars* S, double2& va, double2& vb) {
-    if (VK == VK_S) {
-        va = make_double2(S->alpha[0], S->alpha[1]);
-        vb = make_double2(0.0, 0.0);
+__device__ __forceinline__ VirtualArgs virtual_args(const VirtualIn& V, const KrylovScalars* S) {
+    VirtualArgs A;
+    A.in2 = V.in2;
+    A.in3 = V.in3;
+    A.in4 = V.in4;
+    A.pout = V.pout;
+    A.rout = V.rout;
+    A.uio = V.uio;
+    if (VK == VK_S || VK == VK_S2) {
+        A.va = make_double2(S->alpha[0], S->alpha[1]);
+    } else if (VK == VK_P) {
+        A.va = make_double2(S->beta[0], S->beta[1]);
+        A.vb = make_double2(S->omega[0], S->omega[1]);
     } else {
-        va = make_double2(S->beta[0], S->beta[1]);
-        vb = make_double2(S->omega[0], S->omega[1]);
+        A.va = make_double2(S->alpha[0], S->alpha[1]);
+        A.vb = make_double2(S->omega[0], S->omega[1]);
+        A.vc = make_double2(S->beta[0], S->beta[1]);
     }
+    return A;
 }
-template <bool HAS_PQ, int VK>
-__global__ __launch_bounds__(256) void k_apply_vk(ApplyBatch B, int total_interior, EdgeRowsDev e, VirtualIn V, const double2* __restrict__ xk,
+template <int VK>
+struct VirtualDot {
+    static constexpr int value = VK == VK_S ? DOT_IN_SS : (VK == VK_S2 ? DOT_B2 : DOT_AUX);
+};
+// MINW = workgroups per CU the register allocation must allow.  VK_R needs ~290 registers: with room for two workgroups per CU it
+// spills 37-70 of them to scratch, which a small mesh (one round of workgroups, more of them than CUs) prefers to waiting for a
+// second round (T106: 28.0 against 29.7 us per iteration); a large mesh prefers no spills (4096^2: 874 against 890 us).
+template <bool HAS_PQ, int VK, int MINW>
+__global__ __launch_bounds__(256, MINW) void k_apply_vk(ApplyBatch B, int total_interior, EdgeRowsDev e, VirtualIn V, const double2* __restrict__ xk,
                                                   const double2* __restrict__ pq, double2* __restrict__ out, double* edge_partials, LazyScalars L) {
-    constexpr int DOT = VK == VK_S ? DOT_IN_SS : DOT_AUX;
+    constexpr int DOT = VirtualDot<VK>::value;
     const KrylovScalars* S = lazy_scalars<256>(L);
-    double2 va, vb;
-    virtual_scalars<VK>(S, va, vb);
+    const VirtualArgs A = virtual_args<VK>(V, S);
     if (total_interior < 0 || static_cast<int>(blockIdx.x) < total_interior) {   // workgroup-uniform
         int k = 0;
 #pragma unroll
         for (int q = 1; q < APPLY_BATCH_MAX; ++q)
             if (q < B.n && static_cast<int>(blockIdx.x) >= B.start[q]) k = q;
-        apply_tile<MODE_SCALED, DOT, false, HAS_PQ, 3, true, VK>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], static_cast<int>(blockIdx.x) - B.start[k], va, vb);
+        apply_tile<MODE_SCALED, DOT, false, HAS_PQ, 3, true, VK>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], static_cast<int>(blockIdx.x) - B.start[k], A.va, A.vb, A.vc);
         return;
     }
     const int wg = static_cast<int>(blockIdx.x) - total_interior;
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
-    edge_rows_wg<MODE_SCALED, DOT, VK>(e, wg, threadIdx.x, V.in, xk, pq, V.aux, out, 0.0, acc, V.in2, va, V.in3, vb, V.pout);
-    block_partials<256>(acc, edge_partials + static_cast<size_t>(wg) * MAX_PARTIALS);
+    edge_rows_wg<MODE_SCALED, DOT, VK>(e, wg, threadIdx.x, V.in, xk, pq, V.aux, out, 0.0, acc, A);
+    block_partials<256, (VK == VK_R ? 4 : dot_columns(DOT))>(acc, edge_partials + static_cast<size_t>(wg) * MAX_PARTIALS);
 }
 template <int VK>
 __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows_vk(EdgeRowsDev e, VirtualIn V, const double2* __restrict__ xk, const double2* __restrict__ pq,
                                                              double2* __restrict__ out, double* partials, const KrylovScalars* __restrict__ S) {
-    constexpr int DOT = VK == VK_S ? DOT_IN_SS : DOT_AUX;
-    double2 va, vb;
-    virtual_scalars<VK>(S, va, vb);
+    constexpr int DOT = VirtualDot<VK>::value;
+    const VirtualArgs A = virtual_args<VK>(V, S);
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
-    edge_rows_wg<MODE_SCALED, DOT, VK>(e, blockIdx.x, threadIdx.x, V.in, xk, pq, V.aux, out, 0.0, acc, V.in2, va, V.in3, vb, V.pout);
-    block_partials<EDGE_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
+    edge_rows_wg<MODE_SCALED, DOT, VK>(e, blockIdx.x, threadIdx.x, V.in, xk, pq, V.aux, out, 0.0, acc, A);
+    block_partials<EDGE_BLOCK, (VK == VK_R ? 4 : dot_columns(DOT))>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
 
 
@@ -1214,7 +1316,7 @@ hipError_t launch_apply_edge_blocks(const ApplyBlock* blocks, int n, int mode, i
 
 hipError_t launch_apply_virtual(const ApplyBlock* blocks, int n, const EdgeRowsDev& e, const VirtualIn& V, const double2* xk, const double2* pq, double2* out,
                                 double* edge_partials, const LazyScalars& scal, hipStream_t st) {
-    if (e.nrows == 0 || (V.kind != VK_S && V.kind != VK_P)) return hipErrorInvalidValue;
+    if (e.nrows == 0 || V.kind < VK_S || V.kind > VK_S2) return hipErrorInvalidValue;
     const bool has_pq = pq != nullptr;
     const bool merged = n <= APPLY_BATCH_MAX;   // one launch for everything; else interior groups first, perimeter rows last
     LazyScalars L = scal;
@@ -1237,15 +1339,28 @@ hipError_t launch_apply_virtual(const ApplyBlock* blocks, int n, const EdgeRowsD
         const dim3 grid(merged ? total + e.nwg : total), block(256);
         if (grid.x == 0) continue;
         const int ti = merged ? total : -1;
-#define TM_VK(PQ, K) hipLaunchKernelGGL((k_apply_vk<PQ, K>), grid, block, 0, st, B, ti, e, V, xk, pq, out, edge_partials, L)
+#define TM_VK(PQ, K) hipLaunchKernelGGL((k_apply_vk<PQ, K, 2>), grid, block, 0, st, B, ti, e, V, xk, pq, out, edge_partials, L)
+#define TM_VK1(PQ, K) hipLaunchKernelGGL((k_apply_vk<PQ, K, 1>), grid, block, 0, st, B, ti, e, V, xk, pq, out, edge_partials, L)
         if (V.kind == VK_S) {
             if (has_pq) TM_VK(true, VK_S);
             else TM_VK(false, VK_S);
-        } else {
+        } else if (V.kind == VK_P) {
             if (has_pq) TM_VK(true, VK_P);
             else TM_VK(false, VK_P);
+        } else if (V.kind == VK_R) {
+            if (grid.x > 2048) {
+                if (has_pq) TM_VK1(true, VK_R);
+                else TM_VK1(false, VK_R);
+            } else {
+                if (has_pq) TM_VK(true, VK_R);
+                else TM_VK(false, VK_R);
+            }
+        } else {
+            if (has_pq) TM_VK(true, VK_S2);
+            else TM_VK(false, VK_S2);
         }
 #undef TM_VK
+#undef TM_VK1
         const hipError_t rc = hipGetLastError();
         if (rc != hipSuccess) return rc;
         if (L.nsteps) {   // the first launch has applied and published the pending steps: later ones read the published block
@@ -1256,7 +1371,9 @@ hipError_t launch_apply_virtual(const ApplyBlock* blocks, int n, const EdgeRowsD
     }
     if (!merged) {
         if (V.kind == VK_S) hipLaunchKernelGGL(k_edge_rows_vk<VK_S>, dim3(e.nwg), dim3(EDGE_BLOCK), 0, st, e, V, xk, pq, out, edge_partials, L.S_in);
-        else hipLaunchKernelGGL(k_edge_rows_vk<VK_P>, dim3(e.nwg), dim3(EDGE_BLOCK), 0, st, e, V, xk, pq, out, edge_partials, L.S_in);
+        else if (V.kind == VK_P) hipLaunchKernelGGL(k_edge_rows_vk<VK_P>, dim3(e.nwg), dim3(EDGE_BLOCK), 0, st, e, V, xk, pq, out, edge_partials, L.S_in);
+        else if (V.kind == VK_R) hipLaunchKernelGGL(k_edge_rows_vk<VK_R>, dim3(e.nwg), dim3(EDGE_BLOCK), 0, st, e, V, xk, pq, out, edge_partials, L.S_in);
+        else hipLaunchKernelGGL(k_edge_rows_vk<VK_S2>, dim3(e.nwg), dim3(EDGE_BLOCK), 0, st, e, V, xk, pq, out, edge_partials, L.S_in);
         return hipGetLastError();
     }
     return hipSuccess;
@@ -1441,7 +1558,7 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rhs(EdgeRowsDev e, const do
         acc[0] = bx * bx;
         acc[1] = by * by;
     }
-    if (partials) block_partials<EDGE_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
+    if (partials) block_partials<EDGE_BLOCK, 2>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
 hipError_t launch_edge_rhs(const EdgeRowsDev& e, const double2* xk, const double2* pq, double2* rhs_out, int scaled, double* partials,
                            hipStream_t st) {
@@ -1501,24 +1618,48 @@ hipError_t launch_queue_wait(const uint32_t* counter, uint32_t target, uint32_t*
 // ------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partials, int nwg, double* __restrict__ red) {
-    __shared__ double sh[256][MAX_PARTIALS];
+// Sums of `nwg` partial rows by a 256-thread workgroup -- ONE association whatever the caller: the launched finalize kernels and
+// every workgroup of a kernel that applies pending scalar steps must agree to the bit.  Thread t adds rows t, t + 256, ... (all
+// columns of a row: the loads of a trip are independent, and a small mesh needs one or two trips); thread (g, k) = (t / 8, t % 8)
+// adds column k of the eight thread sums 8 g .. 8 g + 7; thread k adds the 32 group sums of its column in ascending g.  Three
+// barriers and 8 + 32 dependent additions instead of an eight-level tree with a barrier per level: the lazy prologue sits on the
+// critical path of every kernel of a small mesh.  Result in out[0..MAX_PARTIALS) (LDS), visible to all threads on return.
+struct PartialSumsLds {
+    double rows[256][MAX_PARTIALS];
+    double groups[32][MAX_PARTIALS];
+};
+static_assert(MAX_PARTIALS == 8, "sum_partial_rows lays 256 threads out as 32 groups x 8 columns");
+__device__ __forceinline__ void sum_partial_rows(const double* __restrict__ partials, int nwg, PartialSumsLds& sh, double* out) {
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
     for (int i = threadIdx.x; i < nwg; i += 256) {
 #pragma unroll
         for (int k = 0; k < MAX_PARTIALS; ++k) acc[k] += partials[static_cast<size_t>(i) * MAX_PARTIALS + k];
     }
 #pragma unroll
-    for (int k = 0; k < MAX_PARTIALS; ++k) sh[threadIdx.x][k] = acc[k];
+    for (int k = 0; k < MAX_PARTIALS; ++k) sh.rows[threadIdx.x][k] = acc[k];
     __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (threadIdx.x < off) {
+    {
+        const int g = threadIdx.x >> 3, k = threadIdx.x & 7;
+        double a = sh.rows[8 * g][k];
 #pragma unroll
-            for (int k = 0; k < MAX_PARTIALS; ++k) sh[threadIdx.x][k] += sh[threadIdx.x + off][k];
-        }
-        __syncthreads();
+        for (int q = 1; q < 8; ++q) a += sh.rows[8 * g + q][k];
+        sh.groups[g][k] = a;
     }
-    if (threadIdx.x < MAX_PARTIALS) red[threadIdx.x] = sh[0][threadIdx.x];
+    __syncthreads();
+    if (threadIdx.x < MAX_PARTIALS) {
+        double t = sh.groups[0][threadIdx.x];
+#pragma unroll
+        for (int q = 1; q < 32; ++q) t += sh.groups[q][threadIdx.x];
+        out[threadIdx.x] = t;
+    }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void k_finalize(const double* __restrict__ partials, int nwg, double* __restrict__ red) {
+    __shared__ PartialSumsLds sh;
+    __shared__ double tot[MAX_PARTIALS];
+    sum_partial_rows(partials, nwg, sh, tot);
+    if (threadIdx.x < MAX_PARTIALS) red[threadIdx.x] = tot[threadIdx.x];
 }
 hipError_t launch_finalize(const double* partials, int nwg, double* red, hipStream_t st) {
     hipLaunchKernelGGL(k_finalize, dim3(1), dim3(256), 0, st, partials, nwg, red);
@@ -1560,7 +1701,51 @@ __device__ __forceinline__ void scalar_update_body(KrylovScalars* S, const doubl
         if (c == 0) S->iters = 0;
         return;
     }
+    if (step == STEP_INIT2) {   // STEP_INIT for the two-kernel iteration: nothing pending, the first p' is r
+        const double rr = red[c];
+        S->rr[c] = rr;
+        S->rr0[c] = rr;
+        S->rho[c] = rr;
+        S->rho_old[c] = 1.0;
+        S->alpha[c] = S->omega[c] = S->beta[c] = 0.0;
+        S->early[c] = 0;
+        S->done[c] = !(rr > S->tol2[c]) ? 1 : 0;
+        if (c == 0) S->iters = 0;
+        return;
+    }
     if (S->done[c]) return;
+    if (step == STEP_A2) {   // red[0..1] = r_hat . v', red[2..3] = ||r'||^2 of the update that rode in front of this apply
+        const double sigma = red[c], rr = red[2 + c];
+        S->rr[c] = rr;
+        int done = 0;
+        if (rr <= S->tol2[c]) done = 1;
+        else if (S->early[c] == 2 || !(fabs(sigma) > tiny)) done = 2;
+        S->early[c] = 0;
+        if (done) {   // the x / r of this component are final: every later update is a no-op
+            S->done[c] = done;
+            S->alpha[c] = S->omega[c] = S->beta[c] = 0.0;
+        } else {
+            S->alpha[c] = S->rho[c] / sigma;
+        }
+        if (c == 0) S->iters += 1;
+        return;
+    }
+    if (step == STEP_B2) {   // red[0..1] = t.s, red[2..3] = t.t, red[4..5] = r_hat.s, red[6..7] = r_hat.t
+        const double ts = red[c], tt = red[2 + c], hs = red[4 + c], ht = red[6 + c];
+        double omega = 0.0;
+        if (tt > tiny) omega = ts / tt;   // else: s is (numerically) zero -- r' = s, and STEP_A2 sees ||r'||^2 <= tol, or a breakdown
+        const double rho_new = hs - omega * ht;   // = r_hat . (s - omega t) = r_hat . r'
+        S->omega[c] = omega;
+        S->rho_old[c] = S->rho[c];
+        S->rho[c] = rho_new;
+        if (!(fabs(omega) > tiny) || !(fabs(rho_new) > tiny)) {
+            S->early[c] = 2;   // breakdown, unless the pending update turns out to have converged (STEP_A2)
+            S->beta[c] = 0.0;
+        } else {
+            S->beta[c] = (rho_new / S->rho_old[c]) * (S->alpha[c] / omega);
+        }
+        return;
+    }
     if (step == STEP_SIGMA) {   // red = r_hat . v
         const double sigma = red[c];
         if (!(fabs(sigma) > tiny)) {
@@ -1612,24 +1797,11 @@ __global__ void k_scalar_update(KrylovScalars* S, const double* __restrict__ red
 // finalize + scalar update in one launch (single-process handles: nothing has to be all-reduced in between)
 __global__ __launch_bounds__(256) void k_finalize_scalar(const double* __restrict__ partials, int nwg, double* __restrict__ red, KrylovScalars* S, int step,
                                                          double rtol, double atol) {
-    __shared__ double sh[256][MAX_PARTIALS];
-    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
-    for (int i = threadIdx.x; i < nwg; i += 256) {
-#pragma unroll
-        for (int k = 0; k < MAX_PARTIALS; ++k) acc[k] += partials[static_cast<size_t>(i) * MAX_PARTIALS + k];
-    }
-#pragma unroll
-    for (int k = 0; k < MAX_PARTIALS; ++k) sh[threadIdx.x][k] = acc[k];
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {   // same tree as k_finalize: identical sums
-        if (threadIdx.x < off) {
-#pragma unroll
-            for (int k = 0; k < MAX_PARTIALS; ++k) sh[threadIdx.x][k] += sh[threadIdx.x + off][k];
-        }
-        __syncthreads();
-    }
-    if (threadIdx.x < MAX_PARTIALS) red[threadIdx.x] = sh[0][threadIdx.x];
-    if (threadIdx.x < 2) scalar_update_body(S, &sh[0][0], step, rtol, atol, threadIdx.x);
+    __shared__ PartialSumsLds sh;
+    __shared__ double tot[MAX_PARTIALS];
+    sum_partial_rows(partials, nwg, sh, tot);
+    if (threadIdx.x < MAX_PARTIALS) red[threadIdx.x] = tot[threadIdx.x];
+    if (threadIdx.x < 2) scalar_update_body(S, tot, step, rtol, atol, threadIdx.x);
 }
 hipError_t launch_finalize_scalar(const double* partials, int nwg, double* red, KrylovScalars* S, int step, hipStream_t st, double rtol, double atol) {
     hipLaunchKernelGGL(k_finalize_scalar, dim3(1), dim3(256), 0, st, partials, nwg, red, S, step, rtol, atol);
@@ -1645,27 +1817,15 @@ template <int NT>
 __device__ __forceinline__ const KrylovScalars* lazy_scalars(const LazyScalars& L) {
     if (L.nsteps == 0) return L.S_in;   // uniform
     __shared__ KrylovScalars shS;
-    __shared__ double shR[NT][MAX_PARTIALS];
+    __shared__ PartialSumsLds shR;
+    __shared__ double tot[MAX_PARTIALS];
+    static_assert(NT == 256, "sum_partial_rows is written for 256 threads");
     constexpr int NWORDS = sizeof(KrylovScalars) / 4;
     static_assert(sizeof(KrylovScalars) % 4 == 0 && NWORDS <= NT, "scalar block is copied one word per thread");
     if (threadIdx.x < NWORDS) reinterpret_cast<uint32_t*>(&shS)[threadIdx.x] = reinterpret_cast<const uint32_t*>(L.S_in)[threadIdx.x];
     for (int q = 0; q < L.nsteps; ++q) {
-        double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
-        for (int i = threadIdx.x; i < L.st[q].nwg; i += NT) {
-#pragma unroll
-            for (int k = 0; k < MAX_PARTIALS; ++k) acc[k] += L.st[q].partials[static_cast<size_t>(i) * MAX_PARTIALS + k];
-        }
-#pragma unroll
-        for (int k = 0; k < MAX_PARTIALS; ++k) shR[threadIdx.x][k] = acc[k];
-        __syncthreads();
-        for (int off = NT / 2; off > 0; off >>= 1) {   // the tree of k_finalize: the same sums in every workgroup
-            if (static_cast<int>(threadIdx.x) < off) {
-#pragma unroll
-                for (int k = 0; k < MAX_PARTIALS; ++k) shR[threadIdx.x][k] += shR[threadIdx.x + off][k];
-            }
-            __syncthreads();
-        }
-        if (threadIdx.x < 2) scalar_update_body(&shS, &shR[0][0], L.st[q].step, 0.0, 0.0, threadIdx.x);
+        sum_partial_rows(L.st[q].partials, L.st[q].nwg, shR, tot);   // the sums of k_finalize: the same in every workgroup
+        if (threadIdx.x < 2) scalar_update_body(&shS, tot, L.st[q].step, 0.0, 0.0, threadIdx.x);
         __syncthreads();
     }
     if (blockIdx.x == 0 && threadIdx.x < NWORDS) reinterpret_cast<uint32_t*>(L.S_out)[threadIdx.x] = reinterpret_cast<const uint32_t*>(&shS)[threadIdx.x];
@@ -1733,7 +1893,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_s_update(LazyScalars L, const dou
             }
         }
     }
-    block_partials<VEC_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
+    block_partials<VEC_BLOCK, 2>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
 hipError_t launch_s_update(const LazyScalars& S, const double2* r, const double2* v, double2* s, int64_t n, double* partials,
                            hipStream_t st) {
@@ -1780,7 +1940,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_xr_update(LazyScalars L, double2*
             }
         }
     }
-    block_partials<VEC_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
+    block_partials<VEC_BLOCK, 4>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
 hipError_t launch_xr_update(const LazyScalars& S, double2* u, const double2* p_hat, const double2* s_hat, const double2* s, const double2* t, double2* r,
                             const double2* r_hat, int64_t n, double* partials, hipStream_t st) {
@@ -1828,7 +1988,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_xr_update_vs(LazyScalars L, doubl
             }
         }
     }
-    block_partials<VEC_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
+    block_partials<VEC_BLOCK, 4>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
 hipError_t launch_xr_update_vs(const LazyScalars& S, double2* u, const double2* p, const double2* v, const double2* t, double2* r, const double2* r_hat, int64_t n,
                                double* partials, hipStream_t st) {
@@ -1861,7 +2021,7 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_residual_copyback(double2* __rest
             }
         }
     }
-    block_partials<VEC_BLOCK>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
+    block_partials<VEC_BLOCK, 2>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
 hipError_t launch_residual_copyback(double2* xk, const double2* u, int64_t n, double* partials, hipStream_t st) {
     hipLaunchKernelGGL(k_residual_copyback, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, xk, u, n, partials);

@@ -456,10 +456,14 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     // ... and the first apply with the p-update folded in: p and v alternate between two arrays each (see k_apply_vk)
     fuse_p = fuse_s;
     if (const char* e = std::getenv("TM_FUSE_P")) fuse_p = fuse_p && std::atoi(e) != 0;
+    // ... and the whole iteration in two kernels (see picard_bicgstab): r alternates too
+    fuse2 = fuse_p;
+    if (const char* e = std::getenv("TM_FUSE_2")) fuse2 = fuse2 && std::atoi(e) != 0;
     if (fuse_p) {
         p_alt = arena.alloc_n<double2>(static_cast<uint64_t>(n_local));
         v_alt = arena.alloc_n<double2>(static_cast<uint64_t>(n_local));
     }
+    if (fuse2) r_alt = arena.alloc_n<double2>(static_cast<uint64_t>(n_local));
     for (int k = 0; k < (lazy ? 3 : 1); ++k) part_buf[k] = arena.alloc_n<double>(npart);
     partials = part_buf[0];
     red = arena.alloc_n<double>(MAX_PARTIALS);
@@ -745,10 +749,14 @@ void Smoother::apply(const double2* in, double2* out, int mode, int dot, const d
     }
 }
 
-// An apply with the vector update in front of it folded in (single-process handles without a preconditioner): see k_apply_vk.
-//   VK_S: out = D^-1 A (in - alpha in2)                       -> STEP_SS_TSTT
-//   VK_P: out = D^-1 A p', p' = in + beta (in2 - omega in3) stored to pout; r_hat . out -> STEP_SIGMA
-void Smoother::apply_virtual(int kind, const double2* in, const double2* in2, const double2* in3, double2* pout, double2* out) {
+// An apply with the vector update(s) in front of it folded in (single-process handles without a preconditioner): see k_apply_vk.
+//   VK_S:  out = D^-1 A (in - alpha in2)                                          -> STEP_SS_TSTT
+//   VK_P:  out = D^-1 A p', p' = in + beta (in2 - omega in3) stored to pout; r_hat . out -> STEP_SIGMA
+//   VK_R:  the pending x / r update, p' and out = D^-1 A p' (in = r, in2 = v, in3 = t, in4 = p)  -> STEP_A2
+//   VK_S2: VK_S with the sums that also give the next rho                          -> STEP_B2
+void Smoother::apply_virtual(int kind, const double2* in, const double2* in2, const double2* in3, double2* pout, double2* out, const double2* in4, double2* rout,
+                             double2* uio) {
+    const bool dot_aux = kind == VK_P || kind == VK_R || kind == VK_S2;
     std::vector<ApplyBlock> blocks(lp.owned_blocks.size());
     for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
         const int64_t b = lp.owned_blocks[k];
@@ -757,10 +765,13 @@ void Smoother::apply_virtual(int kind, const double2* in, const double2* in2, co
         a.in = in + ls;
         a.in2 = in2 + ls;
         a.in3 = in3 ? in3 + ls : nullptr;
+        a.in4 = in4 ? in4 + ls : nullptr;
         a.pout = pout ? pout + ls : nullptr;
+        a.rout = rout ? rout + ls : nullptr;
+        a.uio = uio ? uio + ls : nullptr;
         a.xk = X + ls;
         a.pq = PQ ? PQ + ls : nullptr;
-        a.aux = kind == VK_P ? r_hat + ls : nullptr;
+        a.aux = dot_aux ? r_hat + ls : nullptr;
         a.out = out + ls;
         a.ni = static_cast<int>(topo.ni[b]);
         a.nj = static_cast<int>(topo.nj[b]);
@@ -773,11 +784,14 @@ void Smoother::apply_virtual(int kind, const double2* in, const double2* in2, co
     V.in = in;
     V.in2 = in2;
     V.in3 = in3;
-    V.aux = kind == VK_P ? r_hat : nullptr;
+    V.in4 = in4;
+    V.aux = dot_aux ? r_hat : nullptr;
     V.pout = pout;
+    V.rout = rout;
+    V.uio = uio;
     HIPCHK(launch_apply_virtual(blocks.data(), static_cast<int>(blocks.size()), edge, V, X, PQ, out, partials + static_cast<size_t>(poff_edge) * MAX_PARTIALS,
                                 scalars_for(), stream));
-    reduce_update(nwg_apply, kind == VK_P ? STEP_SIGMA : STEP_SS_TSTT);
+    reduce_update(nwg_apply, kind == VK_P ? STEP_SIGMA : (kind == VK_S ? STEP_SS_TSTT : (kind == VK_R ? STEP_A2 : STEP_B2)));
 }
 
 void Smoother::white_launch(int update) {
@@ -867,11 +881,12 @@ int Smoother::picard_bicgstab(tm_stats& st) {
     poll_iters = 0;
     while (true) {
         // r = D^-1 (b - A U) ; r_hat = r ; p = v = 0
-        apply(U, r, MODE_RESID, DOT_OUT2, nullptr, X, 0.0, STEP_INIT);
+        apply(U, r, MODE_RESID, DOT_OUT2, nullptr, X, 0.0, fuse2 ? STEP_INIT2 : STEP_INIT);
         st.operator_sweeps += 1;
         HIPCHK(hipMemcpyAsync(r_hat, r, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));
         HIPCHK(hipMemsetAsync(p, 0, sizeof(double2) * n_local, stream));
         HIPCHK(hipMemsetAsync(v, 0, sizeof(double2) * n_local, stream));
+        if (fuse2) HIPCHK(hipMemsetAsync(t, 0, sizeof(double2) * n_local, stream));   // the first pass multiplies it by omega = 0
         if (restarts == 0) {   // scaled nonlinear residual of this outer iteration
             flush_pending();
             HIPCHK(hipMemcpyAsync(h_S, S, sizeof(KrylovScalars), hipMemcpyDeviceToHost, stream));
@@ -886,6 +901,30 @@ int Smoother::picard_bicgstab(tm_stats& st) {
         bool breakdown = false;
         poll_open = false;
         while (it_total < opt.max_inner) {
+            if (fuse2) {
+                // Two kernels per iteration.  (A) in front of the first apply, as the rows enter its window: the x / r update left
+                // pending by the previous iteration (u += alpha p + omega s, r' = s - omega t, s = r - alpha v), then p' = r' +
+                // beta (p - omega v) and v' = D^-1 A p'; sums r_hat.v' and ||r'||^2.  (B) the second apply on s' = r' - alpha' v'
+                // formed the same way, t = D^-1 A s'; sums t.s, t.t, r_hat.s, r_hat.t -- which give omega AND the next rho
+                // (r_hat.r'' = r_hat.s - omega r_hat.t), so no third reduction and no third kernel.  r, p, v alternate between two
+                // arrays each: neighbouring workgroups still read the old values in their halos.
+                apply_virtual(VK_R, r, v, t, p_alt, v_alt, p, r_alt, U);
+                std::swap(r, r_alt);
+                std::swap(p, p_alt);
+                std::swap(v, v_alt);
+                apply_virtual(VK_S2, r, v, nullptr, nullptr, t);
+                st.operator_sweeps += 2;
+                it_total += 1;
+                if (it_total % opt.check_every == 0 || it_total == opt.max_inner) {
+                    const int verdict = poll_done(it_total, it_total == opt.max_inner);
+                    if (verdict) {
+                        converged = verdict == 1;
+                        breakdown = !converged;
+                        break;
+                    }
+                }
+                continue;
+            }
             if (fuse_p) {
                 // p = r + beta (p - omega v) is formed as the rows enter the first apply's window and stored from there; the new p
                 // and v go to the alternate arrays (the halos of neighbouring workgroups still read the old ones)
@@ -939,6 +978,10 @@ int Smoother::picard_bicgstab(tm_stats& st) {
                     break;
                 }
             }
+        }
+        if (fuse2) {   // the last iteration's x / r update is still pending (zero scalars once a component has finished)
+            flush_pending();
+            HIPCHK(launch_xr_update_vs(scalars_for(), U, p, v, t, r, r_hat, n_owned, partials, stream));   // its partial sums are not used
         }
         if (converged || !breakdown || restarts >= 8 || it_total >= opt.max_inner) break;
         restarts += 1;   // breakdown (rho or omega vanished): restart from the current iterate

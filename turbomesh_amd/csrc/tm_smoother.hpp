@@ -157,8 +157,10 @@ struct Smoother {
     int apply_rows = 0;             // K2 rows per chunk of this handle (0 = per-block rule)
     bool fuse_s = false;            // k_apply_vk<VK_S> / k_xr_update_vs instead of k_s_update + apply + k_xr_update
     bool fuse_p = false;            // k_apply_vk<VK_P> instead of k_p_update + apply; p and v alternate with p_alt, v_alt
-    double2 *p_alt = nullptr, *v_alt = nullptr;
-    void apply_virtual(int kind, const double2* in, const double2* in2, const double2* in3, double2* pout, double2* out);
+    bool fuse2 = false;             // two kernels per iteration: k_apply_vk<VK_R> + k_apply_vk<VK_S2>; r alternates with r_alt
+    double2 *p_alt = nullptr, *v_alt = nullptr, *r_alt = nullptr;
+    void apply_virtual(int kind, const double2* in, const double2* in2, const double2* in3, double2* pout, double2* out, const double2* in4 = nullptr,
+                       double2* rout = nullptr, double2* uio = nullptr);
     bool lazy = false;
     double* part_buf[3] = {nullptr, nullptr, nullptr};
     int part_rot = 0;
