@@ -122,8 +122,11 @@ enum {
 enum {
     TM_OPT_SINGLE_SWEEP = 1, /* TM_INNER_RELAX: one kernel pass per sweep.  Default (bit clear): sweeps are taken two per pass
                                 where the blocks allow it (same arithmetic, bit-identical coordinates, half the HBM traffic) */
-    TM_OPT_EAGER_SCALARS = 2 /* Krylov modes: every reduction gets its own scalar-update launch.  Default (bit clear): on small
-                                single-process meshes the update travels with the kernel that consumes it (same sums, same order) */
+    TM_OPT_EAGER_SCALARS = 2 /* Krylov modes: the textbook launch sequence of BiCGStab.zig:279-370 -- one kernel per vector update, one
+                                scalar-update launch per reduction.  Default (bit clear) on single-process handles: the vector updates
+                                are formed inside the two operator applications (two kernels per iteration; rho from r_hat.s -
+                                omega r_hat.t, equal in exact arithmetic) and, on small meshes, the scalar steps travel with the
+                                kernels that consume them.  Same method, iterates equal to rounding */
 };
 typedef struct tm_solver_opt {
     int32_t tag;             /* TM_SOLVER_* */
