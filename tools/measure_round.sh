@@ -27,6 +27,8 @@ PY
   echo "## BASELINE configs[3] / [4] on one GPU"; python3 tools/config4_probe.py 2>/dev/null | tail -2; python3 tools/config5_probe.py 2>/dev/null | tail -2
   echo "## the reference's example inputs as written, 10 Picard iterations, hip solver (tools/t106_probe.py)"
   python3 tools/t106_probe.py T106 2>/dev/null | tail -1; python3 tools/t106_probe.py LS89 2>/dev/null | tail -1
+  echo "## plain BiCGStab (diagonal), time per inner iteration (tools/bicgstab_iter_probe.py)"
+  python3 tools/bicgstab_iter_probe.py 4096 200 2>/dev/null | tail -1; python3 tools/bicgstab_iter_probe.py 1024 500 2>/dev/null | tail -1; python3 tools/bicgstab_iter_probe.py 256 500 2>/dev/null | tail -1
   echo "## perturbed 4096^2 block to a scaled residual <= 1e-8 (tools/solve_probe.py)"; python3 tools/solve_probe.py 4096 1e-6 1e-10 2>/dev/null
   echo "## host-buffer seam, PCIe inclusive (tools/oneshot_probe.py)"; python3 tools/oneshot_probe.py 2>/dev/null | tail -4
 } > "$out" 2>&1
