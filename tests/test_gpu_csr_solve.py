@@ -49,6 +49,13 @@ def test_umfpack_5x5_known_answer():
     assert np.abs(x - np.arange(1, 6)).max() < 1e-9 and np.abs(y - 2 * np.arange(1, 6)).max() < 1e-9
 
 
+def test_petsc_diagonal_known_answer():
+    # petsc.zig:110-178: diag(1, 2) x = (1, 4) -> x = (1, 2), the reference's other sparse-solver known answer (1e-15 there)
+    x, y, rc, st = csr_solve([0, 1, 2], [0, 1], [1.0, 2.0], [1.0, 4.0], [2.0, 8.0], rtol=1e-15, max_inner=50, check_every=1)
+    assert rc == 0, st
+    assert np.abs(x - [1.0, 2.0]).max() <= 1e-15 and np.abs(y - [2.0, 4.0]).max() <= 1e-15
+
+
 def test_spd_laplacian_closed_form_and_warm_start():
     # tridiag(-1,2,-1) x = e_1 -> x_i = (n - i)/(n + 1)
     import scipy.sparse as sp

@@ -73,6 +73,16 @@ def test_umfpack_5x5_kat_all_oracle_solvers():
         assert np.abs(x - np.arange(1, 6)).max() < 1e-9, (kind, pc, x)
 
 
+def test_petsc_diagonal_kat_all_oracle_solvers():
+    # petsc.zig:110-178: diag(1, 2) x = (1, 4) -> (1, 2) within 1e-15
+    b = np.array([1.0, 4.0])
+    x, _, _ = oracle.csr_solve("direct", 2, [0, 1, 2], [0, 1], [1.0, 2.0], b)
+    assert np.abs(x - [1.0, 2.0]).max() <= 1e-15
+    for kind, pc in (("gmres", oracle.PRECOND_ILU0), ("gmres", oracle.PRECOND_DIAGONAL), ("bicgstab", oracle.PRECOND_DIAGONAL), ("bicgstab", oracle.PRECOND_ILU0)):
+        x, it, ok = oracle.csr_solve(kind, 2, [0, 1, 2], [0, 1], [1.0, 2.0], b, precond=pc, rtol=1e-15, atol=1e-15)
+        assert np.abs(x - [1.0, 2.0]).max() <= 1e-15, (kind, pc, x)
+
+
 def test_solvers_on_spd_laplacian_closed_form():
     # 1D Laplacian tridiag(-1,2,-1) x = e_1  ->  x_i = (n - i)/(n + 1), i = 0..n-1
     n = 40
