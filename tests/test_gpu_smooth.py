@@ -245,3 +245,23 @@ def test_two_kernel_iteration_against_the_classic_recurrence(name, monkeypatch):
         capped[mode] = mesh_flat(mesh)
     assert float(np.abs(capped["0"] - capped["1"]).max()) <= 1e-9 * max(1.0, float(np.abs(capped["0"]).max()))
     assert not np.array_equal(capped["1"], mesh_flat(build()))
+
+
+@pytest.mark.parametrize("ni,nj", [(3, 3), (3, 70), (70, 3), (4, 4), (5, 257), (257, 5), (64, 64), (65, 66), (66, 129), (20, 513), (131, 300)])
+def test_two_kernel_iteration_odd_shapes(ni, nj):
+    # k_apply_vk<VK_R> stores r', p', u for the owner of each node as its row ENTERS the window: chunk seams, partial waves, one-row
+    # and one-column blocks.  Five updates (the last one flushed after the loop) against the launch-per-step path: rounding apart.
+    out = []
+    for eager in (True, False):
+        m = configs.single_block(ni, nj, perturb=0.2)
+        with smooth.Smoother(m, solver.Option.hip(rtol=1e-30, max_inner=5, check_every=5, eager_scalars=eager)) as sm:
+            st = sm.iterate(2)
+            sm.download()
+        assert st["inner_iterations"] == 10
+        out.append(m.blocks[0].points.data.copy())
+    assert np.isfinite(out[1]).all()
+    assert float(np.abs(out[0] - out[1]).max()) <= 1e-11
+    seed = configs.single_block(ni, nj, perturb=0.2).blocks[0].points.data
+    assert np.array_equal(out[1][0], seed[0]) and np.array_equal(out[1][:, -1], seed[:, -1])   # fixed boundary untouched
+    if ni > 3 and nj > 3:
+        assert not np.array_equal(out[1][1:-1, 1:-1], seed[1:-1, 1:-1])
