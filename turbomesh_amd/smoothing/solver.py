@@ -48,7 +48,7 @@ class Option:
     check_every: int = 0       # 0 -> 8
     omega: float = 0.0         # 0 -> 1.0
     single_sweep: bool = False # relax: one kernel pass per sweep (default: two sweeps per pass where possible)
-    eager_scalars: bool = False  # Krylov modes: a scalar-update launch per reduction (default: folded into the consuming kernels on small meshes)
+    eager_scalars: bool = False  # Krylov modes: the textbook launch sequence (a kernel per vector update, a launch per scalar step); default: two fused kernels per iteration
 
     @classmethod
     def hip(cls, **kw):
