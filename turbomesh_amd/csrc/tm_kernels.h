@@ -99,14 +99,22 @@ std::vector<int32_t> relax2_border_tiles(int ni, int nj, int rows_per_chunk, int
 enum Relax2Subset { R2_ALL = 0, R2_BORDER = 1, R2_INSIDE_A = 2, R2_INSIDE_B = 3, R2_INSIDE = 4 };
 // lds_bytes: dynamic LDS the launch asks for.  K2x2 needs none; a multi-rank interior pass asks for a third of the CU's 160 KB to cap
 // itself at 3 workgroups per CU (see Smoother::inside_lds).
-hipError_t launch_relax2_block(const Relax2Block& a, int rows_per_chunk, int dot, int subset, hipStream_t stream, size_t lds_bytes = 0);
+// wait: the workgroups spin (one thread each, with sleeps) until *counter >= target before they touch memory -- what a
+// launch_queue_wait in front of the launch would do, without the launch (border passes: a few dozen workgroups).
+struct QueueWait {
+    const uint32_t* counter = nullptr;
+    uint32_t target = 0;
+    uint32_t* error = nullptr;
+};
+hipError_t launch_relax2_block(const Relax2Block& a, int rows_per_chunk, int dot, int subset, hipStream_t stream, size_t lds_bytes = 0,
+                               const QueueWait* wait = nullptr);
 struct Relax2Batch {
     Relax2Block b[8];
     int RI[8], nSG[8], nRC[8], start[8];
     int n;
 };
 hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, int subset, hipStream_t stream,
-                                size_t lds_bytes = 0);
+                                size_t lds_bytes = 0, const QueueWait* wait = nullptr);
 void tune_fuse_rows(int rows);
 
 // ---- K4/K5 perimeter rows.  The rows of an interface are REGULAR: along a connection the row id, every column id and the
@@ -138,8 +146,10 @@ struct EdgeRowsDev {
 };
 constexpr int EDGE_BLOCK = 128;
 // out/in/xk/pq/aux are the rank-local vectors (owned rows then ghost rows)
+// signal != nullptr: the kernel's first thread bumps *signal as it starts -- "everything in front of this launch in its queue is
+// complete and visible device-wide" (what launch_queue_signal would announce from a launch of its own)
 hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const double2* xk, const double2* pq, const double2* aux,
-                            double2* out, double omega, int mode, int dot, double* partials, hipStream_t stream);
+                            double2* out, double omega, int mode, int dot, double* partials, hipStream_t stream, uint32_t* signal = nullptr);
 // interior rows of n <= APPLY_BATCH_MAX blocks + the perimeter rows in one launch (Krylov modes); hipErrorNotSupported = no such kernel
 hipError_t launch_apply_edge_blocks(const ApplyBlock* blocks, int n, int mode, int dot, const EdgeRowsDev& e, const double2* in, const double2* xk,
                                     const double2* pq, const double2* aux, double2* out, double* edge_partials, hipStream_t stream);

@@ -769,7 +769,42 @@ __global__ __launch_bounds__(256) void k_relax2(Relax2Block a, int RI, int nSG, 
     relax2_tile<DOT, U, NT, W1>(a, RI, nSG, nRC, subset, blockIdx.x);
 }
 
+// Ordering against another queue from inside a kernel (Smoother::relax_pairs_pipelined): every workgroup of a WAITED launch spins
+// on the counter before it touches memory, then acquires at agent scope (the producer's kernels ended with a release); the first
+// thread of a SIGNALLING launch publishes that everything in front of the launch in its queue is complete.
+__device__ __forceinline__ void queue_wait_in_kernel(const QueueWait& w) {
+    if (threadIdx.x == 0) {
+        unsigned polls = 0;
+        while (__hip_atomic_load(w.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < w.target) {
+            __builtin_amdgcn_s_sleep(16);
+            if (++polls > (1u << 25)) {   // fail the pass rather than hang the device
+                __hip_atomic_store(w.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                break;
+            }
+        }
+    }
+    __syncthreads();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+}
+__device__ __forceinline__ void queue_signal_in_kernel(uint32_t* counter) {
+    if (counter && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+template <int DOT, int U, bool NT, bool W1>
+__global__ __launch_bounds__(256) void k_relax2_waited(Relax2Block a, int RI, int nSG, int nRC, int subset, QueueWait w) {
+    queue_wait_in_kernel(w);
+    relax2_tile<DOT, U, NT, W1>(a, RI, nSG, nRC, subset, blockIdx.x);
+}
+
 // several blocks of a rank in one launch (see k_apply_batch)
+template <int DOT, int U, bool NT, bool W1>
+__global__ __launch_bounds__(256) void k_relax2_batch_waited(Relax2Batch B, int subset, QueueWait w) {
+    queue_wait_in_kernel(w);
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < APPLY_BATCH_MAX; ++q)
+        if (q < B.n && static_cast<int>(blockIdx.x) >= B.start[q]) k = q;
+    relax2_tile<DOT, U, NT, W1>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], subset, static_cast<int>(blockIdx.x) - B.start[k]);
+}
 template <int DOT, int U, bool NT, bool W1>
 __global__ __launch_bounds__(256) void k_relax2_batch(Relax2Batch B, int subset) {
     int k = 0;
@@ -816,12 +851,23 @@ std::vector<int32_t> relax2_border_tiles(int ni, int nj, int RI, int dyn) {
     }
     return ids;
 }
-hipError_t launch_relax2_block(const Relax2Block& a, int RI, int dot, int subset, hipStream_t st, size_t lds) {
+hipError_t launch_relax2_block(const Relax2Block& a, int RI, int dot, int subset, hipStream_t st, size_t lds, const QueueWait* wait) {
     const int nstrips = (a.nj - 1 + 59) / 60;
     const int nSG = (nstrips + 3) / 4, nRC = relax2_nchunks(a.ni, RI);
-    if (subset == R2_BORDER && a.nborder == 0) return hipSuccess;
+    if (subset == R2_BORDER && a.nborder == 0) return wait ? launch_queue_wait(wait->counter, wait->target, wait->error, st) : hipSuccess;
     const dim3 grid(subset == R2_BORDER ? a.nborder : nSG * nRC), block(256);
     const bool w1 = a.omega == 1.0;
+    if (wait) {
+        const QueueWait w = *wait;
+        if (dot == DOT_DELTA) {
+            if (w1) hipLaunchKernelGGL((k_relax2_waited<DOT_DELTA, R2_U, true, true>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
+            else hipLaunchKernelGGL((k_relax2_waited<DOT_DELTA, R2_U, true, false>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
+        } else {
+            if (w1) hipLaunchKernelGGL((k_relax2_waited<DOT_NONE, R2_U, true, true>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
+            else hipLaunchKernelGGL((k_relax2_waited<DOT_NONE, R2_U, true, false>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
+        }
+        return hipGetLastError();
+    }
     if (dot == DOT_DELTA) {
         if (w1) hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, true>), grid, block, lds, st, a, RI, nSG, nRC, subset);
         else hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, false>), grid, block, lds, st, a, RI, nSG, nRC, subset);
@@ -831,8 +877,9 @@ hipError_t launch_relax2_block(const Relax2Block& a, int RI, int dot, int subset
     }
     return hipGetLastError();
 }
-hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, int subset, hipStream_t st, size_t lds) {
-    if (n == 1) return launch_relax2_block(blocks[0], rows_per_chunk[0], dot, subset, st, lds);
+hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, int subset, hipStream_t st, size_t lds, const QueueWait* wait) {
+    if (n == 1) return launch_relax2_block(blocks[0], rows_per_chunk[0], dot, subset, st, lds, wait);
+    bool waited = false;   // the first launch of the group carries the wait (in-order queue: the later ones follow it)
     for (int first = 0; first < n; first += APPLY_BATCH_MAX) {
         Relax2Batch B;
         B.n = 0;
@@ -851,6 +898,20 @@ hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_c
         for (int q = B.n; q < APPLY_BATCH_MAX; ++q) B.start[q] = total;
         if (total == 0) continue;
         const dim3 grid(total), block(256);
+        if (wait && !waited) {
+            waited = true;
+            const QueueWait w = *wait;
+            if (dot == DOT_DELTA) {
+                if (w1) hipLaunchKernelGGL((k_relax2_batch_waited<DOT_DELTA, R2_U, true, true>), grid, block, lds, st, B, subset, w);
+                else hipLaunchKernelGGL((k_relax2_batch_waited<DOT_DELTA, R2_U, true, false>), grid, block, lds, st, B, subset, w);
+            } else {
+                if (w1) hipLaunchKernelGGL((k_relax2_batch_waited<DOT_NONE, R2_U, true, true>), grid, block, lds, st, B, subset, w);
+                else hipLaunchKernelGGL((k_relax2_batch_waited<DOT_NONE, R2_U, true, false>), grid, block, lds, st, B, subset, w);
+            }
+            const hipError_t rc = hipGetLastError();
+            if (rc != hipSuccess) return rc;
+            continue;
+        }
         if (dot == DOT_DELTA) {
             if (w1) hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, true, true>), grid, block, lds, st, B, subset);
             else hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, true, false>), grid, block, lds, st, B, subset);
@@ -861,6 +922,7 @@ hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_c
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
     }
+    if (wait && !waited) return launch_queue_wait(wait->counter, wait->target, wait->error, st);   // nothing to launch: the wait alone
     return hipSuccess;
 }
 void tune_fuse_rows(int rows) { g_fuse_rows = rows > 0 ? rows : 0; }
@@ -1162,7 +1224,8 @@ template <int MODE, int DOT>
 __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const double2* __restrict__ in,
                                                           const double2* __restrict__ xk, const double2* __restrict__ pq,
                                                           const double2* __restrict__ aux, double2* __restrict__ out, double omega,
-                                                          double* partials) {
+                                                          double* partials, uint32_t* signal) {
+    queue_signal_in_kernel(signal);
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
     edge_rows_wg<MODE, DOT>(e, blockIdx.x, threadIdx.x, in, xk, pq, aux, out, omega, acc);
     if (DOT != DOT_NONE) block_partials<EDGE_BLOCK, dot_columns(DOT)>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
@@ -1257,12 +1320,12 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows_vk(EdgeRowsDev e, Virt
 
 
 hipError_t launch_edge_rows(const EdgeRowsDev& e, const double2* in, const double2* xk, const double2* pq, const double2* aux,
-                            double2* out, double omega, int mode, int dot, double* partials, hipStream_t st) {
-    if (e.nrows == 0) return hipSuccess;
+                            double2* out, double omega, int mode, int dot, double* partials, hipStream_t st, uint32_t* signal) {
+    if (e.nrows == 0) return signal ? launch_queue_signal(signal, st) : hipSuccess;
     const dim3 grid(e.nwg), block(EDGE_BLOCK);
 #define TM_EDGE(M, D)                                                                                                  \
     if (mode == M && dot == D) {                                                                                       \
-        hipLaunchKernelGGL((k_edge_rows<M, D>), grid, block, 0, st, e, in, xk, pq, aux, out, omega, partials);         \
+        hipLaunchKernelGGL((k_edge_rows<M, D>), grid, block, 0, st, e, in, xk, pq, aux, out, omega, partials, signal); \
         return hipGetLastError();                                                                                      \
     }
     TM_EDGE(MODE_RAW, DOT_NONE)

@@ -1007,7 +1007,7 @@ int Smoother::picard_bicgstab(tm_stats& st) {
 //   perimeter rows of X^(k+2)  <- perimeter-row kernel on M (perimeter + ring + exchanged ghost rows are all it reads)
 // With several ranks the K2x2 grid is launched in two parts on two queues (relax_pairs_pipelined): the border workgroups in the
 // latency-critical chain, the rest beside it.
-void Smoother::relax2_launch(int subset, bool counts, int dot, hipStream_t on) {
+void Smoother::relax2_launch(int subset, bool counts, int dot, hipStream_t on, const QueueWait* wait) {
     if (!on) on = stream;
     std::vector<Relax2Block> blocks(lp.owned_blocks.size());
     for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
@@ -1026,7 +1026,7 @@ void Smoother::relax2_launch(int subset, bool counts, int dot, hipStream_t on) {
         a.partials = partials + static_cast<size_t>(poff2[k]) * MAX_PARTIALS;
     }
     const size_t lds = (subset == R2_INSIDE) ? inside_lds : 0;
-    profiled([&]() { HIPCHK(launch_relax2_blocks(blocks.data(), rows2.data(), static_cast<int>(blocks.size()), dot, subset, on, lds)); }, counts, on);
+    profiled([&]() { HIPCHK(launch_relax2_blocks(blocks.data(), rows2.data(), static_cast<int>(blocks.size()), dot, subset, on, lds, wait)); }, counts, on);
 }
 
 // want_partials: only the pass whose displacement norms are read back pays for them (the last one of an iterate() call)
@@ -1097,12 +1097,29 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
         else HIPCHK(hipStreamWaitEvent(side, ev_inside[(upto - 1) & 1], 0));
     };
     const EdgeRowsDev& e1 = edge_nf_g.nrows ? edge_nf_g : edge_nf;
-    auto edge_on_side = [&](const EdgeRowsDev& e, const double2* in, double2* out, int dot) {
-        HIPCHK(launch_edge_rows(e, in, in, PQ, nullptr, out, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, side));
+    auto edge_on_side = [&](const EdgeRowsDev& e, const double2* in, double2* out, int dot, uint32_t* signal = nullptr) {
+        HIPCHK(launch_edge_rows(e, in, in, PQ, nullptr, out, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(poff2_edge) * MAX_PARTIALS, side, signal));
     };
     auto exchange_on_side = [&](double2* vec) {
         exchange(vec, side);
         exchange_finish(side);
+    };
+    // With counters the two dependencies of the chain cost no launch of their own (at 2048^2 and below a pair is bound by the HOST:
+    // ~8 launches plus the transport's calls per pair; rocprofv3 timeline in profiles/): the border pass spins on "interior pass k
+    // is done" in its own prologue (a few dozen workgroups), and "border pass k is done" is published by the first thread of the
+    // perimeter-row launch that follows it in the queue -- the interior pass k+1 that waits for it reads nothing that launch
+    // writes (it touches no row within four of a side whose perimeter rows move) and writes nothing it reads.
+    auto border_pass = [&](uint32_t inside_upto, int dot) {   // border workgroups; inside_upto > 0: after interior passes 0 .. inside_upto-1
+        if (use_flags && inside_upto > 0) {
+            QueueWait w;
+            w.counter = inside_done;
+            w.target = inside_upto;
+            w.error = sync_err;
+            relax2_launch(R2_BORDER, true, dot, side, &w);
+        } else {
+            if (inside_upto > 0) wait_inside(inside_upto);
+            relax2_launch(R2_BORDER, true, dot, side);
+        }
     };
     // K2x2 parts read X (input) and write U (output) through relax2_launch: keep X/U pointing at the pair in flight
     int dot = (npairs == 1 && want_partials_last) ? DOT_DELTA : DOT_NONE;
@@ -1111,12 +1128,17 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
     edge_on_side(e1, X, M, DOT_NONE);    // E1g(0): perimeter rows (own + ghost) of the intermediate field
     relax2_launch(R2_INSIDE, false, dot);
     if (!use_flags || npairs == 1) signal_inside();   // with counters the announcement travels with the next wait (one launch)
-    relax2_launch(R2_BORDER, true, dot, side);
+    border_pass(0, dot);
     for (uint64_t k = 0; k < npairs; ++k) {
-        edge_on_side(edge_nf, M, U, dot);             // E2(k): perimeter rows of the pair's output (ghost operands: M's ghost rows)
-        // "the border workgroups of pair k are done" -- announced BEHIND E2: the interior pass k+1 that waits for it cannot start before
-        // interior pass k has ended anyway, long after this point, and the chain is one launch shorter in front of the exchange
-        if (k + 1 < npairs) signal_border();
+        // E2(k): perimeter rows of the pair's output (ghost operands: M's ghost rows); with counters it also announces border pass k
+        const bool announce = k + 1 < npairs;
+        if (use_flags && announce) {
+            edge_on_side(edge_nf, M, U, dot, border_done);
+            n_border += 1;
+        } else {
+            edge_on_side(edge_nf, M, U, dot);
+            if (announce) signal_border();
+        }
         std::swap(X, U);
         if (k + 1 == npairs) {
             fence(side, stream, ev_to_main);          // the main stream continues behind the whole chain
@@ -1135,8 +1157,7 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
         if (!use_flags) signal_inside();
         exchange_on_side(X);
         edge_on_side(e1, X, M, DOT_NONE);             // E1g(k+1)
-        wait_inside(static_cast<uint32_t>(k + 1));    // border k+1 reads rows interior pass k wrote, and overwrites ITS input
-        relax2_launch(R2_BORDER, true, dot, side);
+        border_pass(static_cast<uint32_t>(k + 1), dot);   // border k+1 reads rows interior pass k wrote, and overwrites ITS input
     }
     if (use_flags) {
         HIPCHK(hipMemcpyAsync(h_flags, sync_flags, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, stream));

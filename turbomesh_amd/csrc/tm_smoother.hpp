@@ -178,7 +178,7 @@ struct Smoother {
     void relax_sweeps(uint64_t n, tm_stats& st);
     void relax_pair(bool want_partials);
     void profiled(const std::function<void()>& launch, bool counts = true, hipStream_t on = nullptr);
-    void relax2_launch(int subset, bool counts, int dot, hipStream_t on = nullptr);
+    void relax2_launch(int subset, bool counts, int dot, hipStream_t on = nullptr, const QueueWait* wait = nullptr);
 };
 
 }  // namespace tmh
