@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 
 from oracle import oracle
-from tests.conftest import OracleMesh, mesh_flat
+from tests.conftest import OracleMesh, mesh_flat, oracle_tfi
 from tests.meshes import TOPOLOGIES
 from turbomesh_amd import configs
 from turbomesh_amd.smoothing import smooth, solver, wall_control_function as wcf
@@ -265,3 +265,19 @@ def test_two_kernel_iteration_odd_shapes(ni, nj):
     assert np.array_equal(out[1][0], seed[0]) and np.array_equal(out[1][:, -1], seed[:, -1])   # fixed boundary untouched
     if ni > 3 and nj > 3:
         assert not np.array_equal(out[1][1:-1, 1:-1], seed[1:-1, 1:-1])
+
+
+def test_more_blocks_than_one_batch_launch_holds():
+    # > 8 owned blocks: the interior rows go out in groups of 8 and the perimeter rows in a launch of their own (the unmerged form of
+    # the fused BiCGStab kernels: lazy scalar steps published by the first launch, read by the later ones) -- vs the exact-solve oracle
+    build = lambda tfi=None: configs.strip(11, 14, 23, reverse_odd=True, tfi=tfi)
+    om = OracleMesh(build(oracle_tfi))
+    oracle.picard_exact(om, 3)
+    for eager in (False, True):
+        mesh = build()
+        with smooth.Smoother(mesh, solver.Option.hip(rtol=1e-13, max_inner=5000, eager_scalars=eager)) as sm:
+            st = sm.iterate(3)
+            sm.download()
+        assert st["not_converged"] == 0
+        rms = float(np.sqrt(np.mean((mesh_flat(mesh) - om.flat()) ** 2)))
+        assert rms <= 1e-10, (eager, rms)
