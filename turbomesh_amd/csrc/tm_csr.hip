@@ -159,7 +159,11 @@ extern "C" int tm_csr_solve(uint64_t n64, const int32_t* Ap, const int32_t* Ai, 
         Dev d_p(sizeof(int32_t) * (static_cast<size_t>(n) + 1)), d_i(sizeof(int32_t) * nnz), d_vx(sizeof(double) * nnz), d_vy(two ? sizeof(double) * nnz : 0);
         Dev d_dinv(vb), d_b(vb), d_u(vb), d_r(vb), d_rh(vb), d_pv(vb), d_v(vb), d_s(vb), d_t(vb), d_tmp(sizeof(double) * 2 * static_cast<size_t>(n));
         const int nwg = (n + 255) / 256, nwg_vec = vec_nwg(n);
-        Dev d_part(sizeof(double) * MAX_PARTIALS * static_cast<size_t>(std::max(nwg, nwg_vec))), d_red(sizeof(double) * MAX_PARTIALS), d_S(sizeof(KrylovScalars));
+        // small systems are bound by dependent launches: the scalar steps travel with the kernels that consume them (LazyScalars,
+        // tm_kernels.h; three partial-sum buffers in rotation, two scalar blocks) -- 5 launches per iteration instead of 9
+        const int npart = std::max(nwg, nwg_vec);
+        const bool lazy = npart <= 512 && !(opt.flags & TM_OPT_EAGER_SCALARS);
+        Dev d_part(sizeof(double) * MAX_PARTIALS * static_cast<size_t>(npart) * (lazy ? 3 : 1)), d_red(sizeof(double) * MAX_PARTIALS), d_S(sizeof(KrylovScalars) * 2);
         hipStream_t st = nullptr;
         HIPCHK(hipMemcpyAsync(d_p.p, Ap, sizeof(int32_t) * (static_cast<size_t>(n) + 1), hipMemcpyHostToDevice, st));
         HIPCHK(hipMemcpyAsync(d_i.p, Ai, sizeof(int32_t) * nnz, hipMemcpyHostToDevice, st));
@@ -178,10 +182,42 @@ extern "C" int tm_csr_solve(uint64_t n64, const int32_t* Ap, const int32_t* Ai, 
         hipLaunchKernelGGL(k_csr_dinv, dim3(nwg), dim3(256), 0, st, n, A.p, A.i, A.vx, A.vy, d_dinv.as<double2>());
         HIPCHK(hipGetLastError());
 
-        double* partials = d_part.as<double>();
+        double* part_buf[3] = {d_part.as<double>(), d_part.as<double>() + (lazy ? 1 : 0) * MAX_PARTIALS * static_cast<size_t>(npart),
+                               d_part.as<double>() + (lazy ? 2 : 0) * MAX_PARTIALS * static_cast<size_t>(npart)};
+        int part_rot = 0;
+        double* partials = part_buf[0];
         double* red = d_red.as<double>();
-        KrylovScalars* S = d_S.as<KrylovScalars>();
-        HIPCHK(hipMemsetAsync(S, 0, sizeof(KrylovScalars), st));
+        KrylovScalars* S_buf[2] = {d_S.as<KrylovScalars>(), d_S.as<KrylovScalars>() + 1};
+        KrylovScalars* S = S_buf[0];
+        HIPCHK(hipMemsetAsync(S_buf[0], 0, sizeof(KrylovScalars) * 2, st));
+        LazyStep pending[2];
+        int npending = 0;
+        auto flush_pending = [&]() {   // pending steps applied by launches of their own (before the host reads the scalars)
+            for (int q = 0; q < npending; ++q) HIPCHK(launch_finalize_scalar(pending[q].partials, pending[q].nwg, red, S, pending[q].step, st));
+            npending = 0;
+        };
+        auto reduce_update = [&](int nrows, int step) {   // the partial rows just written feed scalar step `step`
+            if (!lazy) {
+                HIPCHK(launch_finalize_scalar(partials, nrows, red, S, step, st));
+                return;
+            }
+            if (npending == 2) flush_pending();
+            pending[npending++] = LazyStep{step, partials, nrows};
+            part_rot = (part_rot + 1) % 3;
+            partials = part_buf[part_rot];   // the next producer writes elsewhere: this buffer is read by the consumer's workgroups
+        };
+        auto scalars_for = [&]() {   // for a kernel that reads the scalars: it applies the pending steps itself and publishes the result
+            LazyScalars L;
+            L.S_in = S;
+            if (npending == 0) return L;
+            KrylovScalars* other = (S == S_buf[0]) ? S_buf[1] : S_buf[0];
+            L.S_out = other;
+            L.nsteps = npending;
+            for (int q = 0; q < npending; ++q) L.st[q] = pending[q];
+            npending = 0;
+            S = other;
+            return L;
+        };
         double2 *u = d_u.as<double2>(), *r = d_r.as<double2>(), *r_hat = d_rh.as<double2>(), *p = d_pv.as<double2>(), *v = d_v.as<double2>(),
                 *s = d_s.as<double2>(), *t = d_t.as<double2>();
         hipLaunchKernelGGL(k_csr_bnorm, dim3(nwg), dim3(256), 0, st, n, d_b.as<double2>(), A.dinv, partials);
@@ -190,6 +226,7 @@ extern "C" int tm_csr_solve(uint64_t n64, const int32_t* Ap, const int32_t* Ai, 
 
         KrylovScalars h_S;
         auto read_S = [&]() {
+            flush_pending();
             HIPCHK(hipMemcpyAsync(&h_S, S, sizeof(KrylovScalars), hipMemcpyDeviceToHost, st));
             HIPCHK(hipStreamSynchronize(st));
         };
@@ -200,6 +237,7 @@ extern "C" int tm_csr_solve(uint64_t n64, const int32_t* Ap, const int32_t* Ai, 
         while (true) {
             hipLaunchKernelGGL((k_csr_apply<true, DOT_OUT2>), dim3(nwg), dim3(256), 0, st, A, u, d_b.as<double2>(), nullptr, r, partials);
             HIPCHK(hipGetLastError());
+            flush_pending();
             HIPCHK(launch_finalize_scalar(partials, nwg, red, S, STEP_INIT, st));
             HIPCHK(hipMemcpyAsync(r_hat, r, vb, hipMemcpyDeviceToDevice, st));
             HIPCHK(hipMemsetAsync(p, 0, vb, st));
@@ -215,17 +253,17 @@ extern "C" int tm_csr_solve(uint64_t n64, const int32_t* Ap, const int32_t* Ai, 
             }
             bool breakdown = false;
             while (it_total < opt.max_inner) {
-                HIPCHK(launch_p_update(plain_scalars(S), r, p, v, n, st));
+                HIPCHK(launch_p_update(scalars_for(), r, p, v, n, st));
                 hipLaunchKernelGGL((k_csr_apply<false, DOT_AUX>), dim3(nwg), dim3(256), 0, st, A, p, nullptr, r_hat, v, partials);
                 HIPCHK(hipGetLastError());
-                HIPCHK(launch_finalize_scalar(partials, nwg, red, S, STEP_SIGMA, st));
-                HIPCHK(launch_s_update(plain_scalars(S), r, v, s, n, partials, st));
-                HIPCHK(launch_finalize_scalar(partials, nwg_vec, red, S, STEP_SS, st));
+                reduce_update(nwg, STEP_SIGMA);
+                HIPCHK(launch_s_update(scalars_for(), r, v, s, n, partials, st));
+                reduce_update(nwg_vec, STEP_SS);
                 hipLaunchKernelGGL((k_csr_apply<false, DOT_IN>), dim3(nwg), dim3(256), 0, st, A, s, nullptr, nullptr, t, partials);
                 HIPCHK(hipGetLastError());
-                HIPCHK(launch_finalize_scalar(partials, nwg, red, S, STEP_TSTT, st));
-                HIPCHK(launch_xr_update(plain_scalars(S), u, p, s, s, t, r, r_hat, n, partials, st));
-                HIPCHK(launch_finalize_scalar(partials, nwg_vec, red, S, STEP_RHO, st));
+                reduce_update(nwg, STEP_TSTT);
+                HIPCHK(launch_xr_update(scalars_for(), u, p, s, s, t, r, r_hat, n, partials, st));
+                reduce_update(nwg_vec, STEP_RHO);
                 it_total += 1;
                 if (it_total % opt.check_every == 0 || it_total == opt.max_inner) {
                     read_S();
