@@ -163,13 +163,20 @@ def solve_to_tolerance(n, smooth, solver, configs, tol=1e-8):
     """BASELINE configs[1] read literally -- "fp64 elliptic smoothing to 1e-8 residual": the perturbed n x n block (SURVEY 8d
     config 2, displacement 0.25 h, seed 12345) driven to a scaled nonlinear residual <= 1e-8 by Picard + multigrid-preconditioned
     BiCGStab.  Reported beside the headline metric, outside its timed region."""
-    mesh = configs.single_block(n, n, perturb=0.25)
     # inexact Picard: the inner tolerance only has to carry the NONLINEAR residual below `tol` (tools/solve_probe.py: rtol 1e-6
-    # reaches it in one outer iteration with 2 inner iterations; 1e-10 needs 5 for the same residual, 1e-4 stalls above it)
-    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-6, check_every=1)) as sm:
-        reached, st = sm.iterate_until(tol, 50)
+    # reaches it in one outer iteration with 2 inner iterations; 1e-10 needs 5 for the same residual, 1e-4 stalls above it).
+    # The job runs twice on identical fresh meshes: the first call of a process also loads ~20 kernel variants (the coarse
+    # multigrid levels use their own), ~50 us each on first launch; `seconds` is the second run, the first is reported beside it.
+    first = None
+    for rep in range(2):
+        mesh = configs.single_block(n, n, perturb=0.25)
+        with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-6, check_every=1)) as sm:
+            reached, st = sm.iterate_until(tol, 50)
+        if rep == 0:
+            first = st["seconds"]
     return {"reached": bool(reached), "tolerance": tol, "outer_iterations": st["outer_iterations"], "inner_iterations": st["inner_iterations"],
-            "operator_sweeps": st["operator_sweeps"], "seconds": st["seconds"], "scaled_residual_rms": st["scaled_residual_rms"],
+            "operator_sweeps": st["operator_sweeps"], "seconds": st["seconds"], "seconds_first_call_in_process": first,
+            "scaled_residual_rms": st["scaled_residual_rms"],
             "inner_rtol": 1e-6, "solver": "hip/mg_bicgstab (Picard + BiCGStab, one multigrid V(2,2) cycle per block as preconditioner)"}
 
 
