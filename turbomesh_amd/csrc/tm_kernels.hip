@@ -270,6 +270,8 @@ __device__ __forceinline__ double2 virtual_vec(double2 x, double2 y, double2 z, 
     return x;
 }
 
+__device__ __forceinline__ double2 load_nt(const double2* src);   // defined with the vector kernels
+
 // One workgroup's tile of one block; `bid` = the workgroup's index within that block's tiles (also its partial-sum slot).
 // VK (virtual input vector, formed as the rows are taken into the window; va, vb component-wise):
 //   VK_S: in - va * in2                (s = r - alpha v, never stored)
@@ -550,7 +552,7 @@ __device__ __forceinline__ double2 relax_row(const Row3& m, const Row3& c, const
 // inside path below -- straight-line steps, loads one group ahead, every predicate folded into a select or into the offset of
 // a buffer store -- because a workgroup on the edge that waits out the full memory latency at every step would still be running
 // long after the rest of the launch has drained.
-template <int DOT, int U, bool NT, bool W1>
+template <int DOT, int U, int NT, bool W1>
 __device__ __forceinline__ void relax2_strip_edge(const Relax2Block& a, const Relax2Tile& t, double (&acc)[MAX_PARTIALS]) {
     const int ni = a.ni, nj = a.nj;
     const int cc = min(max(t.c, 0), nj - 1);
@@ -607,7 +609,7 @@ __device__ __forceinline__ void relax2_strip_edge(const Relax2Block& a, const Re
             const double2 o = relax_row<W1>(S[A0], S[A1], S[A2], a.omega, d2);
             const bool live = t.out_lane && (i >= t.i0) && (i < t.i1);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, o), out_rsrc,
-                                                   static_cast<int>(live ? lane_off + static_cast<unsigned>((i - t.i0) * nj * 16) : OOB_VOFFSET), 0, NT ? 2 : 0);
+                                                   static_cast<int>(live ? lane_off + static_cast<unsigned>((i - t.i0) * nj * 16) : OOB_VOFFSET), 0, (NT & 1) ? 2 : 0);
             if (DOT == DOT_DELTA) {
                 if (!live) d2 = zero;
                 accumulate<DOT_DELTA>(acc, S[A1].c, o, d2);
@@ -626,12 +628,17 @@ __device__ __forceinline__ void relax2_strip_edge(const Relax2Block& a, const Re
 // also wait for the stores issued since.  Hence: lane predication of the store by a buffer store whose masked lanes carry an
 // out-of-range offset (dropped by the hardware), no row predicates, the next group's rows requested before this group's
 // arithmetic, and the first group peeled so that both loop entries see the same queue of outstanding operations.
-template <int DOT, int U, bool NT, bool W1>
+template <int DOT, int U, int NT, bool W1>
 __device__ __forceinline__ void relax2_strip_inside(const Relax2Block& a, const Relax2Tile& t, double (&acc)[MAX_PARTIALS]) {
     const int nj = a.nj;
     const double2* in_col = a.in + t.c;
     const int last_row = t.i1 + 1;   // last row of `in` this strip needs; prefetches past it re-read it
-    auto load_in = [&](int row) { return in_col[static_cast<size_t>(min(row, last_row)) * nj]; };
+    // NT & 2: streaming loads -- the interior pass of a multi-rank sweep pair on a small block, so that it stops evicting what the
+    // chain's kernels re-read (costs the pass its own L2 hits on the rows neighbouring chunks share: see DESIGN.md section 6)
+    auto load_in = [&](int row) {
+        const double2* src = in_col + static_cast<size_t>(min(row, last_row)) * nj;
+        return (NT & 2) ? load_nt(src) : *src;
+    };
     const __amdgpu_buffer_rsrc_t out_rsrc =
         __builtin_amdgcn_make_buffer_rsrc(a.out + static_cast<size_t>(t.i0) * nj, 0, (t.i1 - t.i0) * nj * 16, 0x00020000);
     const unsigned voff = t.out_lane ? static_cast<unsigned>(t.c) * 16u : OOB_VOFFSET;
@@ -673,7 +680,7 @@ __device__ __forceinline__ void relax2_strip_inside(const Relax2Block& a, const 
             acc[2] += o.x + o.y;   // diagnostic build: no stores
 #else
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, o), out_rsrc, static_cast<int>(voff + static_cast<unsigned>((tb + u) * nj * 16)), 0,
-                                                   NT ? 2 : 0);
+                                                   (NT & 1) ? 2 : 0);
 #endif
             if (DOT == DOT_DELTA) {
                 if (!t.out_lane) d2 = make_double2(0.0, 0.0);   // masked lanes hold garbage (possibly non-finite): select, never multiply
@@ -726,7 +733,7 @@ __host__ __device__ inline bool relax2_tile_is_border(int ni, int nj, int i0, in
     return (top && (dyn & 1)) || (bottom && (dyn & 2)) || (left && (dyn & 4)) || (right && (dyn & 8));
 }
 
-template <int DOT, int U, bool NT, bool W1>
+template <int DOT, int U, int NT, bool W1>
 __device__ __forceinline__ void relax2_tile(const Relax2Block& a, int RI, int nSG, int nRC, int subset, int bid) {
     static_assert(U % 3 == 0, "windows rotate by renaming");
     const int lane = threadIdx.x & 63;
@@ -764,7 +771,7 @@ __device__ __forceinline__ void relax2_tile(const Relax2Block& a, int RI, int nS
     if (DOT != DOT_NONE) block_partials<256, dot_columns(DOT)>(acc, a.partials + static_cast<size_t>(logical) * MAX_PARTIALS);   // slot = tile id in every launch flavour
 }
 
-template <int DOT, int U, bool NT, bool W1>
+template <int DOT, int U, int NT, bool W1>
 __global__ __launch_bounds__(256) void k_relax2(Relax2Block a, int RI, int nSG, int nRC, int subset) {
     relax2_tile<DOT, U, NT, W1>(a, RI, nSG, nRC, subset, blockIdx.x);
 }
@@ -789,14 +796,14 @@ __device__ __forceinline__ void queue_wait_in_kernel(const QueueWait& w) {
 __device__ __forceinline__ void queue_signal_in_kernel(uint32_t* counter) {
     if (counter && blockIdx.x == 0 && threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-template <int DOT, int U, bool NT, bool W1>
+template <int DOT, int U, int NT, bool W1>
 __global__ __launch_bounds__(256) void k_relax2_waited(Relax2Block a, int RI, int nSG, int nRC, int subset, QueueWait w) {
     queue_wait_in_kernel(w);
     relax2_tile<DOT, U, NT, W1>(a, RI, nSG, nRC, subset, blockIdx.x);
 }
 
 // several blocks of a rank in one launch (see k_apply_batch)
-template <int DOT, int U, bool NT, bool W1>
+template <int DOT, int U, int NT, bool W1>
 __global__ __launch_bounds__(256) void k_relax2_batch_waited(Relax2Batch B, int subset, QueueWait w) {
     queue_wait_in_kernel(w);
     int k = 0;
@@ -805,7 +812,7 @@ __global__ __launch_bounds__(256) void k_relax2_batch_waited(Relax2Batch B, int 
         if (q < B.n && static_cast<int>(blockIdx.x) >= B.start[q]) k = q;
     relax2_tile<DOT, U, NT, W1>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], subset, static_cast<int>(blockIdx.x) - B.start[k]);
 }
-template <int DOT, int U, bool NT, bool W1>
+template <int DOT, int U, int NT, bool W1>
 __global__ __launch_bounds__(256) void k_relax2_batch(Relax2Batch B, int subset) {
     int k = 0;
 #pragma unroll
@@ -860,20 +867,26 @@ hipError_t launch_relax2_block(const Relax2Block& a, int RI, int dot, int subset
     if (wait) {
         const QueueWait w = *wait;
         if (dot == DOT_DELTA) {
-            if (w1) hipLaunchKernelGGL((k_relax2_waited<DOT_DELTA, R2_U, true, true>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
-            else hipLaunchKernelGGL((k_relax2_waited<DOT_DELTA, R2_U, true, false>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
+            if (w1) hipLaunchKernelGGL((k_relax2_waited<DOT_DELTA, R2_U, 1, true>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
+            else hipLaunchKernelGGL((k_relax2_waited<DOT_DELTA, R2_U, 1, false>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
         } else {
-            if (w1) hipLaunchKernelGGL((k_relax2_waited<DOT_NONE, R2_U, true, true>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
-            else hipLaunchKernelGGL((k_relax2_waited<DOT_NONE, R2_U, true, false>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
+            if (w1) hipLaunchKernelGGL((k_relax2_waited<DOT_NONE, R2_U, 1, true>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
+            else hipLaunchKernelGGL((k_relax2_waited<DOT_NONE, R2_U, 1, false>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
         }
         return hipGetLastError();
     }
+    // lds > 0 = the capped interior pass of a multi-rank sweep pair on a small block: streaming loads (relax2_strip_inside)
+    if (lds > 0 && w1) {
+        if (dot == DOT_DELTA) hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, 3, true>), grid, block, lds, st, a, RI, nSG, nRC, subset);
+        else hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, 3, true>), grid, block, lds, st, a, RI, nSG, nRC, subset);
+        return hipGetLastError();
+    }
     if (dot == DOT_DELTA) {
-        if (w1) hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, true>), grid, block, lds, st, a, RI, nSG, nRC, subset);
-        else hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, true, false>), grid, block, lds, st, a, RI, nSG, nRC, subset);
+        if (w1) hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, 1, true>), grid, block, lds, st, a, RI, nSG, nRC, subset);
+        else hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, 1, false>), grid, block, lds, st, a, RI, nSG, nRC, subset);
     } else {
-        if (w1) hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, true, true>), grid, block, lds, st, a, RI, nSG, nRC, subset);
-        else hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, true, false>), grid, block, lds, st, a, RI, nSG, nRC, subset);
+        if (w1) hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, 1, true>), grid, block, lds, st, a, RI, nSG, nRC, subset);
+        else hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, 1, false>), grid, block, lds, st, a, RI, nSG, nRC, subset);
     }
     return hipGetLastError();
 }
@@ -902,22 +915,29 @@ hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_c
             waited = true;
             const QueueWait w = *wait;
             if (dot == DOT_DELTA) {
-                if (w1) hipLaunchKernelGGL((k_relax2_batch_waited<DOT_DELTA, R2_U, true, true>), grid, block, lds, st, B, subset, w);
-                else hipLaunchKernelGGL((k_relax2_batch_waited<DOT_DELTA, R2_U, true, false>), grid, block, lds, st, B, subset, w);
+                if (w1) hipLaunchKernelGGL((k_relax2_batch_waited<DOT_DELTA, R2_U, 1, true>), grid, block, lds, st, B, subset, w);
+                else hipLaunchKernelGGL((k_relax2_batch_waited<DOT_DELTA, R2_U, 1, false>), grid, block, lds, st, B, subset, w);
             } else {
-                if (w1) hipLaunchKernelGGL((k_relax2_batch_waited<DOT_NONE, R2_U, true, true>), grid, block, lds, st, B, subset, w);
-                else hipLaunchKernelGGL((k_relax2_batch_waited<DOT_NONE, R2_U, true, false>), grid, block, lds, st, B, subset, w);
+                if (w1) hipLaunchKernelGGL((k_relax2_batch_waited<DOT_NONE, R2_U, 1, true>), grid, block, lds, st, B, subset, w);
+                else hipLaunchKernelGGL((k_relax2_batch_waited<DOT_NONE, R2_U, 1, false>), grid, block, lds, st, B, subset, w);
             }
             const hipError_t rc = hipGetLastError();
             if (rc != hipSuccess) return rc;
             continue;
         }
+        if (lds > 0 && w1) {   // see launch_relax2_block
+            if (dot == DOT_DELTA) hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, 3, true>), grid, block, lds, st, B, subset);
+            else hipLaunchKernelGGL((k_relax2_batch<DOT_NONE, R2_U, 3, true>), grid, block, lds, st, B, subset);
+            const hipError_t e = hipGetLastError();
+            if (e != hipSuccess) return e;
+            continue;
+        }
         if (dot == DOT_DELTA) {
-            if (w1) hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, true, true>), grid, block, lds, st, B, subset);
-            else hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, true, false>), grid, block, lds, st, B, subset);
+            if (w1) hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, 1, true>), grid, block, lds, st, B, subset);
+            else hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, 1, false>), grid, block, lds, st, B, subset);
         } else {
-            if (w1) hipLaunchKernelGGL((k_relax2_batch<DOT_NONE, R2_U, true, true>), grid, block, lds, st, B, subset);
-            else hipLaunchKernelGGL((k_relax2_batch<DOT_NONE, R2_U, true, false>), grid, block, lds, st, B, subset);
+            if (w1) hipLaunchKernelGGL((k_relax2_batch<DOT_NONE, R2_U, 1, true>), grid, block, lds, st, B, subset);
+            else hipLaunchKernelGGL((k_relax2_batch<DOT_NONE, R2_U, 1, false>), grid, block, lds, st, B, subset);
         }
         const hipError_t e = hipGetLastError();
         if (e != hipSuccess) return e;
