@@ -75,3 +75,30 @@ def test_harness_csr_slot_known_answer():
     r = subprocess.run([HARNESS, "csr"], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "csr kat: rc 0" in r.stdout
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver_name", ["relax", "bicgstab"])
+def test_harness_drives_the_rccl_transport(tmp_path, solver_name):
+    # a compiled caller through tm_rccl_unique_id / tm_rccl_comm_create / tm_rccl_hooks (the one-GPU box allows a one-rank
+    # communicator: rendezvous by file, hooks filled by the library, handle created with them) == the same job without hooks.
+    # relax: bit for bit; bicgstab: the hooked handle runs the launch-per-step recurrence, the plain one the two-kernel one.
+    import torch
+
+    env = dict(os.environ, TM_LIBRCCL=os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so"))
+    its = "7" if solver_name == "relax" else "2"
+    d1, d2 = str(tmp_path / "ranks.bin"), str(tmp_path / "plain.bin")
+    r = subprocess.run([HARNESS, "ranks", "1", "0", str(tmp_path / "id"), "2", "40", "130", its, solver_name, d1], capture_output=True, text=True, timeout=180, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "rank 0 of 1" in r.stdout
+    r = subprocess.run([HARNESS, "strip", "2", "40", "130", its, solver_name, d2], capture_output=True, text=True, timeout=180)
+    assert r.returncode == 0, r.stderr
+    a, b = np.fromfile(d1, dtype=np.float64), np.fromfile(d2, dtype=np.float64)
+    assert a.shape == b.shape == (2 * 40 * 130 * 2,)
+    if solver_name == "relax":
+        assert np.array_equal(a, b)
+    else:
+        assert float(np.sqrt(np.mean((a - b) ** 2))) <= 2e-10
+    # rank outside the job / fewer blocks than ranks: refused before anything collective happens
+    r = subprocess.run([HARNESS, "ranks", "2", "2", str(tmp_path / "id2"), "2", "40", "130", "1"], capture_output=True, text=True, timeout=60, env=env)
+    assert r.returncode == 1 and "error(" in r.stderr

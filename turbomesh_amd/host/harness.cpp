@@ -4,14 +4,20 @@
 //   tm_harness strip <nblocks> <ni> <nj> <iterations> [relax|bicgstab|mg] [until <tol>] [write <file.xyz>] [dump.bin]
 //   tm_harness single <ni> <nj> <iterations> [relax|bicgstab|mg] [until <tol>] [write <file.xyz>] [dump.bin]
 //   tm_harness csr                                     the linear-solver slot (seam 2) on the reference's 5 x 5 known answer
+//   tm_harness ranks <world> <rank> <idfile> <nblocks> <ni> <nj> <iterations> [relax|bicgstab] [dump.bin]
+//        one process per GPU (start each with HIP_VISIBLE_DEVICES=<its GPU>): the strip's blocks are dealt to the ranks in order, the
+//        interface rows travel by the library's own RCCL transport (tm_rccl_*); rank 0 writes the ncclUniqueId to <idfile>, the
+//        others wait for it (the rendezvous a Zig caller would do over MPI or a file); dump.bin = this rank's OWNED blocks
 //
 // The synthetic edges are those of SURVEY.md 8d (config 2 / config 4), identical to turbomesh_amd/configs.py.
 // dump.bin (optional): all block coordinates as raw f64 after smoothing, for the parity test.
 #include "turbomesh.hpp"
 
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <thread>
 
 using namespace core;
 using discrete::Block2d;
@@ -113,9 +119,72 @@ static int csrKat() {
     return (rc == 0 && err < 1e-9) ? 0 : 1;
 }
 
+// One rank of a multi-process run through the library's RCCL transport, from a compiled caller (what distributed.RcclHooks does
+// from Python): unique id by file, communicator, hooks for this partition, handle, iterate, download the owned blocks.
+static int runRank(int argc, char** argv) {
+    if (argc < 9) throw Error(TM_E_ARG, "ranks <world> <rank> <idfile> <nblocks> <ni> <nj> <iterations> [relax|bicgstab] [dump.bin]");
+    const int world = std::atoi(argv[2]), rank = std::atoi(argv[3]);
+    const std::string idfile = argv[4];
+    const std::size_t nb = std::strtoull(argv[5], nullptr, 10), ni = std::strtoull(argv[6], nullptr, 10), nj = std::strtoull(argv[7], nullptr, 10);
+    const std::size_t iterations = std::strtoull(argv[8], nullptr, 10);
+    if (world < 1 || rank < 0 || rank >= world || nb < static_cast<std::size_t>(world)) throw Error(TM_E_ARG, "ranks: need 0 <= rank < world <= nblocks");
+    int a = 9;
+    smoothing::solver::Option opt;
+    if (a < argc && std::strcmp(argv[a], "relax") == 0) opt.inner = TM_INNER_RELAX;
+    if (a < argc && (std::strcmp(argv[a], "relax") == 0 || std::strcmp(argv[a], "bicgstab") == 0)) ++a;
+    opt.rtol = 1e-13;
+    opt.max_inner = 5000;
+    const char* librccl = std::getenv("TM_LIBRCCL");   // the copy the process should use; unset = default search
+    unsigned char id[TM_RCCL_ID_BYTES];
+    if (rank == 0) {
+        check(tm_rccl_unique_id(librccl, id));
+        const std::string tmp = idfile + ".tmp";
+        std::FILE* f = std::fopen(tmp.c_str(), "wb");
+        if (!f || std::fwrite(id, 1, sizeof(id), f) != sizeof(id)) throw Error(TM_E_ARG, "cannot write " + tmp);
+        std::fclose(f);
+        if (std::rename(tmp.c_str(), idfile.c_str()) != 0) throw Error(TM_E_ARG, "cannot publish " + idfile);
+    } else {
+        bool got = false;
+        for (int tries = 0; tries < 6000 && !got; ++tries) {   // up to a minute
+            if (std::FILE* f = std::fopen(idfile.c_str(), "rb")) {
+                got = std::fread(id, 1, sizeof(id), f) == sizeof(id);
+                std::fclose(f);
+            }
+            if (!got) std::this_thread::sleep_for(std::chrono::milliseconds(10));
+        }
+        if (!got) throw Error(TM_E_ARG, "no unique id appeared in " + idfile);
+    }
+    tm_rccl_comm* comm = nullptr;
+    check(tm_rccl_comm_create(librccl, id, rank, world, &comm));
+    discrete::Mesh mesh = buildStrip(nb, ni, nj);
+    std::vector<int32_t> owner(nb);
+    for (std::size_t b = 0; b < nb; ++b) owner[b] = static_cast<int32_t>(b * static_cast<std::size_t>(world) / nb);
+    tm_stats st{};
+    {
+        smoothing::smooth::Desc d(mesh);   // the partition's exchange plan is derived from the same description the handle gets
+        tm_comm_hooks hooks{};
+        check(tm_rccl_hooks(comm, &d.desc, owner.data(), &hooks));
+        smoothing::smooth::Smoother sm(mesh, opt, smoothing::wall_control_function::Algorithm::laplace(), &hooks);
+        st = sm.iterate(iterations);
+        sm.download();
+    }
+    tm_rccl_comm_destroy(comm);
+    std::printf("rank %d of %d: outer %llu inner %llu not_converged %d last_residual %.17g\n", rank, world, static_cast<unsigned long long>(st.outer_iterations),
+                static_cast<unsigned long long>(st.inner_iterations), st.not_converged, st.last_residual);
+    if (a < argc) {
+        std::FILE* f = std::fopen(argv[a], "wb");
+        if (!f) throw Error(TM_E_ARG, "cannot open dump file");
+        for (std::size_t b = 0; b < nb; ++b)
+            if (owner[b] == rank) std::fwrite(mesh.blocks[b].points.data.data(), sizeof(Vec2d), mesh.blocks[b].points.data.size(), f);
+        std::fclose(f);
+    }
+    return 0;
+}
+
 int main(int argc, char** argv) {
     try {
         if (argc >= 2 && std::strcmp(argv[1], "csr") == 0) return csrKat();
+        if (argc >= 2 && std::strcmp(argv[1], "ranks") == 0) return runRank(argc, argv);
         if (argc < 5) {
             std::fprintf(stderr, "usage: %s strip <nblocks> <ni> <nj> <iterations> [relax|bicgstab|mg] [until <tol>] [write <file.xyz>] [dump.bin]\n       %s single <ni> <nj> <iterations> [relax|bicgstab|mg] [until <tol>] [write <file.xyz>] [dump.bin]\n", argv[0], argv[0]);
             return 2;

@@ -294,11 +294,14 @@ inline tm_stats mesh(discrete::Mesh& mesh_data, std::size_t iterations, const so
 // reference, or until the scaled nonlinear residual reaches a tolerance; write() = system.write (smooth.zig:396-414).
 class Smoother {
    public:
-    Smoother(discrete::Mesh& mesh_data, const solver::Option& o, const wall_control_function::Algorithm& a) : mesh_(mesh_data), d_(mesh_data) {
+    // hooks: the transport of a multi-process run (one process per GPU), e.g. filled by tm_rccl_hooks; nullptr = all blocks here
+    Smoother(discrete::Mesh& mesh_data, const solver::Option& o, const wall_control_function::Algorithm& a, const tm_comm_hooks* hooks = nullptr)
+        : mesh_(mesh_data), d_(mesh_data) {
         tm_solver_opt so = toOpt(o);
         tm_control_fn cf = toControl(a);
-        check(tm_smoother_create(&d_.desc, &so, &cf, nullptr, nullptr, &h_));
+        check(tm_smoother_create(&d_.desc, &so, &cf, hooks, nullptr, &h_));
     }
+    const tm_mesh_desc& desc() const { return d_.desc; }
     ~Smoother() { tm_smoother_destroy(h_); }
     Smoother(const Smoother&) = delete;
     Smoother& operator=(const Smoother&) = delete;
