@@ -171,3 +171,56 @@ def test_o4h_white_from_the_json_vs_exact_picard(name):
     # north_star: 1e-10 RMS.  (P,Q) pass through acos/atan2/sqrt: glibc on the oracle side, ocml on the device, Zig's
     # std.math in the reference -- ulp-level differences in (P,Q), see DESIGN.md section 2
     assert worst <= 1e-10, worst
+
+
+def test_block_larger_than_two_gibibytes_per_vector():
+    # 8200 x 16384 nodes = 2.15 GB per double2 vector: every byte offset past row 8192 needs more than 31 bits.  (The device holds
+    # 288 GB; BASELINE's sizes are far below, the index arithmetic must not be what limits a user.)  K2x2 and K2 against the oracle's
+    # mirror on windows around and beyond the 2^31-byte line and in the far corner; the two BiCGStab recurrences against each other.
+    ni, nj = 8200, 16384
+    seed = configs.single_block(ni, nj)
+    x0 = seed.blocks[0].points.data
+    assert x0.nbytes > 2**31
+    wins = [(slice(8150, 8200), slice(16200, 16384)), (slice(8185, 8200), slice(0, 140)), (slice(8100, 8170), slice(7000, 7135)),
+            (slice(0, 70), slice(16250, 16384))]
+    keep = [np.ascontiguousarray(x0[r, c]).copy() for r, c in wins]
+    edge_last = x0[-1].copy()
+
+    def check(field, sweeps):
+        for (r, c), w0 in zip(wins, keep):
+            full_r = slice(r.start, r.stop)
+            ref = w0.copy()
+            oracle.time_relax_sweeps(ref, sweeps, 1.0)
+            lo_i = 1 if full_r.start == 0 else sweeps
+            hi_i = 1 if full_r.stop == ni else sweeps
+            lo_j = 1 if c.start == 0 else sweeps
+            hi_j = 1 if c.stop == nj else sweeps
+            inner = (slice(lo_i, ref.shape[0] - hi_i), slice(lo_j, ref.shape[1] - hi_j))
+            got = field[r, c]
+            assert np.array_equal(got[inner], ref[inner]), (r, c, float(np.abs(got[inner] - ref[inner]).max()))
+            assert not np.array_equal(got[inner], w0[inner])
+
+    with smooth.Smoother(seed, _relax(False)) as sm:      # K2x2: one pair
+        sm.iterate(2)
+        sm.download()
+    check(seed.blocks[0].points.data, 2)
+    assert np.array_equal(seed.blocks[0].points.data[-1], edge_last)
+    fresh = configs.single_block(ni, nj)
+    with smooth.Smoother(fresh, _relax(True)) as sm:      # K2: one sweep
+        sm.iterate(1)
+        sm.download()
+    check(fresh.blocks[0].points.data, 1)
+    del fresh
+    # Krylov kernels (row-entry stores of the two-kernel iteration, perimeter-row runs, vector kernels) with 64-bit offsets
+    out = []
+    for eager in (True, False):
+        m = configs.single_block(ni, nj)
+        with smooth.Smoother(m, solver.Option.hip(rtol=1e-30, max_inner=3, check_every=3, eager_scalars=eager)) as sm:
+            st = sm.iterate(1)
+            sm.download()
+        assert st["inner_iterations"] == 3
+        out.append(m.blocks[0].points.data)
+    assert np.isfinite(out[1]).all()
+    assert float(np.abs(out[0] - out[1]).max()) <= 1e-11
+    tfi = configs.single_block(ni, nj).blocks[0].points.data
+    assert not np.array_equal(out[1][8190:8199, 100:200], tfi[8190:8199, 100:200])   # rows past the 2^31-byte line did move
