@@ -111,3 +111,31 @@ def test_smallest_blocks(ni, nj):
     mesh = _block(base.copy())
     st = smooth.mesh(mesh, 2, solver.Option.hip(rtol=1e-13))
     assert st["not_converged"] == 0 and float(np.sqrt(np.mean((mesh_flat(mesh) - om.flat()) ** 2))) <= 1e-10
+
+
+def test_empty_and_undersized_inputs_are_refused_not_crashed():
+    # an empty mesh, a block with no interior node, a connection shorter than the reference's iterators allow (lenInternal() > 3 is
+    # asserted there, smooth.zig:627-631): error codes through the C ABI, never an abort or a launch
+    from turbomesh_amd import _capi
+    from turbomesh_amd.boundary import Connection, Range, Side
+
+    with pytest.raises(_capi.TmError) as e:
+        smooth.mesh(Mesh(), 1, solver.Option.hip())
+    assert e.value.code in (_capi.TM_E_ARG, _capi.TM_E_SIZE)
+    for shape in ((2, 9), (9, 2), (1, 1)):
+        arr = np.zeros(shape + (2,))
+        with pytest.raises(_capi.TmError) as e:
+            smooth.mesh(_block(arr), 1, solver.Option.hip())
+        assert e.value.code in (_capi.TM_E_ARG, _capi.TM_E_SIZE, _capi.TM_E_UNSUPPORTED), shape
+    # zero iterations: nothing moves, nothing is launched that could fail
+    base = configs.single_block(9, 11, perturb=0.2).blocks[0].points.data.copy()
+    mesh = _block(base.copy())
+    st = smooth.mesh(mesh, 0, solver.Option.hip())
+    assert st["outer_iterations"] == 0 and np.array_equal(mesh.blocks[0].points.data, base)
+    # two blocks whose connection names ranges of different lengths
+    two = configs.strip(2, 9, 12)
+    c = two.connections[0]
+    two.connections[0] = Connection((c.ranges[0], Range(c.ranges[1].block, c.ranges[1].side, 0, 7)), c.periodicity)
+    with pytest.raises(_capi.TmError) as e:
+        smooth.mesh(two, 1, solver.Option.hip())
+    assert e.value.code in (_capi.TM_E_TOPOLOGY, _capi.TM_E_MISMATCH, _capi.TM_E_SIZE)
