@@ -113,3 +113,20 @@ def test_converged_coordinates_match_cpu(name):
         sm.download()
     assert reached, st
     assert _rms(mesh_flat(mesh), om.flat()) <= 1e-10
+
+
+@pytest.mark.parametrize("shape", [(129, 257), (100, 131), (67, 300), (33, 33), (5, 70), (300, 9)])
+def test_prolongation_folded_into_the_post_smoothing_sweep_is_bit_identical(shape, monkeypatch):
+    # the correction interpolated as the rows enter K2's window (even / odd rows and columns, wave seams at columns 64 k, semi-coarsened
+    # levels of stretched blocks, halo columns) against the stand-alone k_mg_prolong_add: same expression, same bits
+    out = []
+    for fused in ("2", "0"):   # 2 = the folded form on every level, 0 = never
+        monkeypatch.setenv("TM_MG_FUSE_PROLONG", fused)
+        mesh = configs.single_block(shape[0], shape[1], perturb=0.25)
+        with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-12, max_inner=200, check_every=1)) as sm:
+            st = sm.iterate(2)
+            sm.download()
+        assert st["not_converged"] == 0
+        out.append((mesh.blocks[0].points.data.copy(), st["inner_iterations"]))
+    assert out[0][1] == out[1][1]
+    assert np.array_equal(out[0][0], out[1][0])

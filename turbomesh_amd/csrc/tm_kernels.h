@@ -49,6 +49,8 @@ struct ApplyBlock {
     double2* rout = nullptr;        // VK_R: the updated residual (owned rows)
     double2* uio = nullptr;         // VK_R: the solution vector, updated in place (owned rows)
     int rows = 0;                   // rows per chunk; 0 = the per-block rule (rows_per_chunk, tm_kernels.hip)
+    // VK_PRO (launch_mg_prolong_smooth): in2 = the coarse correction, (nic, njc) its size, ci / cj = which directions were coarsened
+    int mg_nic = 0, mg_njc = 0, mg_ci = 0, mg_cj = 0;
     const double2* in;    // vector the operator acts on, pointing at the block's node (0,0)
     const double2* xk;    // frozen coordinates the coefficients are built from (== in for field mode)
     const double2* pq;    // control function (P,Q) or nullptr (Laplace)
@@ -165,7 +167,7 @@ hipError_t launch_apply_edge_blocks(const ApplyBlock* blocks, int n, int mode, i
 //                out = D^-1 A p'; r', p' stored to rout, pout (arrays other than in, in4), u in place; partial sums r_hat . out and
 //                ||r'||^2 (STEP_A2).  in = r, in2 = v, in3 = t, in4 = p, aux = r_hat.
 //   kind 4 (s2): kind 1 with the partial sums t.s, t.t, r_hat.s, r_hat.t (DOT_B2, STEP_B2), aux = r_hat
-constexpr int VK_NONE = 0, VK_S = 1, VK_P = 2, VK_R = 3, VK_S2 = 4;
+constexpr int VK_NONE = 0, VK_S = 1, VK_P = 2, VK_R = 3, VK_S2 = 4, VK_PRO = 5;
 struct VirtualIn {
     int kind;
     const double2 *in, *in2, *in3, *aux;
@@ -287,6 +289,10 @@ hipError_t launch_mg_inject(const double2* fine, double2* coarse, const MgPair& 
 // f_c = (s_i s_j)^2 * full weighting (1/4 1/2 1/4 per coarsened direction) of the UNscaled fine residual, divided by the coarse
 // diagonal (from the coarse coordinates X_coarse); interior coarse nodes, perimeter untouched (0)
 hipError_t launch_mg_restrict(const double2* r_fine, const double2* X_coarse, double2* f_coarse, const MgPair& g, hipStream_t stream);
+// First post-smoothing sweep of a level with the prolongation in front of it folded in: out = e' + omega (f - D^-1 A e'),
+// e' = e_fine + bilinear interpolation of e_coarse formed as the rows enter K2's window (k_mg_prolong_add's expression: the same
+// bits), e' itself never stored.  a.in = e_fine, a.in2 = e_coarse, a.aux = f, a.xk / a.pq = the level's frozen field.
+hipError_t launch_mg_prolong_smooth(const ApplyBlock& a, const MgPair& g, hipStream_t stream);
 // e_fine += bilinear interpolation of e_coarse, interior fine nodes
 hipError_t launch_mg_prolong_add(const double2* e_coarse, double2* e_fine, const MgPair& g, hipStream_t stream);
 // out = omega * f on interior nodes, 0 on the perimeter: the first damped-Jacobi sweep from a zero guess

@@ -335,11 +335,54 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
             return q.pn;
         };
         auto halo_r = [&](double2 x, double2 y, double2 z, double2 w) { return virtual_r(x, y, z, w, va, vb, vc).pn; };
+        // VK_PRO: e' = e + bilinear interpolation of the coarse correction (k_mg_prolong_add).  Per fine row two coarse rows (ci0,
+        // ci1); per lane the coarse column cj0 of its own column -- the column cj1 is the right neighbour's cj0 when the fine column
+        // is odd (lane shift), its own otherwise.  Edge lanes fetch one more coarse value for their halo column.
+        const int pro_cj0 = (VK == VK_PRO) ? (a.mg_cj ? (jc >> 1) : jc) : 0;
+        const int pro_hc = (VK == VK_PRO) ? min(a.mg_cj ? ((lane == 0) ? ((j0 - 1) >> 1) : ((j0 + 64) >> 1)) : hcol, a.mg_njc - 1) : 0;
+        const bool pro_odd = (VK == VK_PRO) && a.mg_cj && (jc & 1);
+        const bool pro_col = (j >= 1) && (j <= nj - 2);
+        const bool pro_hcol = (lane == 0) ? (j0 - 1 >= 1) : (j0 + 64 <= nj - 2);
+        auto load_coarse = [&](int row, int which, double2& c, double2& h) {   // which = 0: coarse row ci0, 1: ci1
+            const int cr = min(a.mg_ci ? ((row + which) >> 1) : row, a.mg_nic - 1);
+            const double2* rp = a.in2 + static_cast<size_t>(cr) * a.mg_njc;
+            c = rp[max(pro_cj0, 0) < a.mg_njc ? max(pro_cj0, 0) : a.mg_njc - 1];
+            h = make_double2(0.0, 0.0);
+            if (edge_lane) h = rp[max(pro_hc, 0)];
+        };
+        // e (centre, halo) of fine row `row` + the interpolated correction
+        auto prolonged = [&](int row, double2 ec, double2 eh, double2 c0, double2 h0, double2 c1, double2 h1, double2& out_c, double2& out_h) {
+            const bool row_in = (row >= 1) && (row <= ni - 2);
+            // centre: a = (ci0, cj0), b = (ci0, cj1), c = (ci1, cj0), d = (ci1, cj1)
+            const double2 n0 = lane_next(h0, c0), n1 = lane_next(h1, c1);   // shifts first, with every lane active; then the select
+            const double2 b0 = pro_odd ? n0 : c0, b1 = pro_odd ? n1 : c1;
+            out_c = ec;
+            if (row_in && pro_col) {
+                out_c.x += 0.25 * ((c0.x + b0.x) + (c1.x + b1.x));
+                out_c.y += 0.25 * ((c0.y + b0.y) + (c1.y + b1.y));
+            }
+            // halo column (edge lanes): left = j0 - 1 (odd when coarsened: a = its own coarse column, b = lane 0's), right = j0 + 64 (even)
+            out_h = eh;
+            if (edge_lane && row_in && pro_hcol) {
+                const bool left_odd = (lane == 0) && a.mg_cj;
+                const double2 a0 = h0, a1 = h1, q0 = left_odd ? c0 : h0, q1 = left_odd ? c1 : h1;
+                out_h.x += 0.25 * ((a0.x + q0.x) + (a1.x + q1.x));
+                out_h.y += 0.25 * ((a0.y + q0.y) + (a1.y + q1.y));
+            }
+        };
         {
             double2 h0, h1;
             load_row(a.in, i0 - 1, Wc[0], h0);
             load_row(a.in, i0, Wc[1], h1);
-            if (VK == VK_R) {
+            if (VK == VK_PRO) {
+                double2 a0, b0, a1, b1, c0, d0, c1, d1;
+                load_coarse(i0 - 1, 0, a0, b0);
+                load_coarse(i0 - 1, 1, a1, b1);
+                load_coarse(i0, 0, c0, d0);
+                load_coarse(i0, 1, c1, d1);
+                prolonged(i0 - 1, Wc[0], h0, a0, b0, a1, b1, Wc[0], h0);
+                prolonged(i0, Wc[1], h1, c0, d0, c1, d1, Wc[1], h1);
+            } else if (VK == VK_R) {
                 double2 q0, g0, q1, g1, z0, y0, z1, y1, w0, k0, w1, k1;
                 load_row(a.in2, i0 - 1, q0, g0);
                 load_row(a.in2, i0, q1, g1);
@@ -380,7 +423,7 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
 
         struct Group {
             double2 pc[U], ph[U], xpc[U], xph[U], pqv[U], auxv[U], qc[VK != VK_NONE ? U : 1], qh[VK != VK_NONE ? U : 1];
-            double2 zc[(VK == VK_P || VK == VK_R) ? U : 1], zh[(VK == VK_P || VK == VK_R) ? U : 1], wc[VK == VK_R ? U : 1], wh[VK == VK_R ? U : 1], uc[VK == VK_R ? U : 1];
+            double2 zc[(VK == VK_P || VK == VK_R || VK == VK_PRO) ? U : 1], zh[(VK == VK_P || VK == VK_R || VK == VK_PRO) ? U : 1], wc[VK == VK_R ? U : 1], wh[VK == VK_R ? U : 1], uc[VK == VK_R ? U : 1];
         };
         auto load_group = [&](int ib, Group& g) {   // rows ib+1 .. ib+U of the vector (and of xk), pq/aux of rows ib .. ib+U-1
 #pragma unroll
@@ -391,7 +434,12 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
                     g.ph[u] = Wh[1];
                 } else
                     load_row(a.in, prow, g.pc[u], g.ph[u]);
-                if (VK != VK_NONE) load_row(a.in2, prow, g.qc[u], g.qh[u]);
+                if (VK == VK_PRO) {   // the two coarse rows of this fine row (qc/qh: ci0, zc/zh: ci1)
+                    load_coarse(prow, 0, g.qc[u], g.qh[u]);
+                    load_coarse(prow, 1, g.zc[u], g.zh[u]);
+                } else if (VK != VK_NONE) {
+                    load_row(a.in2, prow, g.qc[u], g.qh[u]);
+                }
                 if (VK == VK_P || VK == VK_R) load_row(a.in3, prow, g.zc[u], g.zh[u]);
                 if (VK == VK_R) {
                     load_row(a.in4, prow, g.wc[u], g.wh[u]);
@@ -411,7 +459,9 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
                 const int M = u % 3, C = (u + 1) % 3, P3 = (u + 2) % 3;   // window slots of rows i-1, i, i+1
                 const int row = ib + u;
                 double2 nc, nh;
-                if (VK == VK_R) {
+                if (VK == VK_PRO) {
+                    prolonged(row + 1, g.pc[u], g.ph[u], g.qc[u], g.qh[u], g.zc[VK == VK_PRO ? u : 0], g.zh[VK == VK_PRO ? u : 0], nc, nh);
+                } else if (VK == VK_R) {
                     nc = enter(row + 1, row + 1 < i1, g.pc[u], g.qc[u], g.zc[VK == VK_R ? u : 0], g.wc[VK == VK_R ? u : 0], g.uc[VK == VK_R ? u : 0]);
                     nh = halo_r(g.ph[u], g.qh[u], g.zh[VK == VK_R ? u : 0], g.wh[VK == VK_R ? u : 0]);
                 } else {
@@ -509,6 +559,28 @@ __global__ __launch_bounds__(256) void k_apply_batch(ApplyBatch B) {
     apply_tile<MODE, DOT, FIELD, HAS_PQ, U, NT>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], static_cast<int>(blockIdx.x) - B.start[k]);
 }
 
+
+// Multigrid: the first post-smoothing sweep of a level with the prolongation folded in (VK_PRO, tm_kernels.h)
+template <bool HAS_PQ>
+__global__ __launch_bounds__(256) void k_apply_prolong_smooth(ApplyBlock a, int RI, int nSG, int nRC) {
+    apply_tile<MODE_MG_SMOOTH, DOT_NONE, false, HAS_PQ, 3, true, VK_PRO>(a, RI, nSG, nRC, blockIdx.x);
+}
+static inline int rows_per_chunk(int ni, int nj, int rows);
+hipError_t launch_mg_prolong_smooth(const ApplyBlock& a0, const MgPair& g, hipStream_t st) {
+    if (a0.ni < 3 || a0.nj < 3) return hipSuccess;
+    ApplyBlock a = a0;
+    a.mg_nic = g.nic;
+    a.mg_njc = g.njc;
+    a.mg_ci = g.ci;
+    a.mg_cj = g.cj;
+    const int RI = rows_per_chunk(a.ni, a.nj, a.rows);
+    const int nSG = (a.nj + 255) / 256;
+    const int nRC = (a.ni - 2 + RI - 1) / RI;
+    const dim3 grid(nSG * nRC), block(256);
+    if (a.pq) hipLaunchKernelGGL(k_apply_prolong_smooth<true>, grid, block, 0, st, a, RI, nSG, nRC);
+    else hipLaunchKernelGGL(k_apply_prolong_smooth<false>, grid, block, 0, st, a, RI, nSG, nRC);
+    return hipGetLastError();
+}
 
 // ------------------------------------------------------------------------------------------
 // K2x2: two fused Jacobi sweeps per pass (temporal blocking in registers).
@@ -951,7 +1023,7 @@ void tune_fuse_rows(int rows) { g_fuse_rows = rows > 0 ? rows : 0; }
 // (a round trip per 3 rows), not by bandwidth: it gets the shortest chunks (multiples of the 3-row load group) that keep the launch
 // within 512 workgroups = two per CU (T106, 8 blocks of 10^2..10^4 nodes: 42.5 -> 29.7 us per BiCGStab iteration with 3 rows
 // instead of 18; a 1024^2 block, 9 rows: 88 -> 81 us; with 1024 workgroups the lazy scalar steps no longer apply: 95 us).  `rows` > 0: the caller's choice (a handle that looked at all of its blocks, Smoother::create).
-static inline int rows_per_chunk(int ni, int nj, int rows = 0) {
+static inline int rows_per_chunk(int ni, int nj, int rows) {
     const int interior = ni - 2;
     int RI = rows > 0 ? rows : g_rows_per_chunk;
     if (rows <= 0 && !g_rows_forced) {

@@ -41,6 +41,10 @@ void BlockMG::build(DeviceArena& arena, int ni, int nj, bool has_pq, double aspe
             omega = w;
         }
     }
+    if (const char* e = std::getenv("TM_MG_FUSE_PROLONG")) {   // 0 = never, 1 = wherever it pays (default), 2 = on every level (tests)
+        fuse_prolong = std::atoi(e) != 0;
+        fuse_prolong_min = std::atoi(e) == 2 ? 0 : fuse_prolong_min;
+    }
     L.clear();
     MgLevel l0;
     l0.ni = ni;
@@ -183,8 +187,28 @@ void BlockMG::vcycle(const double2* f0, double2* z, double2* w0, double2* w1, hi
     }
     // ---- up
     for (size_t l = nl - 1; l-- > 0;) {
-        HIPCHK(launch_mg_prolong_add(cur[l + 1], cur[l], pair(l), st));
-        sweeps(l, nu_post);
+        // (levels of a few hundred thousand nodes and more: below that both forms are launch-bound and the plain pair is as fast)
+        if (fuse_prolong && nu_post >= 1 && static_cast<int64_t>(L[l].ni) * L[l].nj >= fuse_prolong_min) {
+            // the correction is interpolated as the rows of the iterate enter the first post-smoothing sweep's window (the same
+            // expression, the same bits as k_mg_prolong_add); the prolonged iterate itself is never stored
+            ApplyBlock a;
+            a.in = cur[l];
+            a.in2 = cur[l + 1];
+            a.xk = L[l].X;
+            a.pq = L[l].PQ;
+            a.aux = rhs[l];
+            a.out = oth[l];
+            a.ni = L[l].ni;
+            a.nj = L[l].nj;
+            a.omega = omega;
+            a.partials = nullptr;
+            HIPCHK(launch_mg_prolong_smooth(a, pair(l), st));
+            std::swap(cur[l], oth[l]);
+            sweeps(l, nu_post - 1);
+        } else {
+            HIPCHK(launch_mg_prolong_add(cur[l + 1], cur[l], pair(l), st));
+            sweeps(l, nu_post);
+        }
     }
     if (cur[0] != z) throw TmError(TM_E_ARG, "internal: multigrid result landed in the scratch block");
 }

@@ -28,6 +28,8 @@ struct MgLevel {
 class BlockMG {
    public:
     int nu_pre = 2, nu_post = 2, nu_coarsest = 8;
+    int64_t fuse_prolong_min = 262144;   // nodes of a level from which the folded form is used
+    bool fuse_prolong = true;   // the prolongation formed inside the first post-smoothing sweep (launch_mg_prolong_smooth); TM_MG_FUSE_PROLONG=0: k_mg_prolong_add
     double omega = 0.8;
     // level 0 buffers are the caller's; coarser levels are carved from the arena
     // aspect = mean g11/g22 of the block's cells (1 = unknown / isotropic); worst_case = size the arena for any aspect
