@@ -130,3 +130,19 @@ def test_prolongation_folded_into_the_post_smoothing_sweep_is_bit_identical(shap
         out.append((mesh.blocks[0].points.data.copy(), st["inner_iterations"]))
     assert out[0][1] == out[1][1]
     assert np.array_equal(out[0][0], out[1][0])
+
+
+def test_folded_prolongation_with_a_control_function_and_many_blocks(monkeypatch):
+    # the (P, Q) flavour of the folded kernel and multi-block meshes: the White plate and T106 (8 blocks, semi-coarsened levels)
+    for build, control in ((TOPOLOGIES["plate_le"], wcf.Algorithm(wcf.White(0.02))), (lambda: load("T106", None)[1], None)):
+        out = []
+        for fused in ("2", "0"):
+            monkeypatch.setenv("TM_MG_FUSE_PROLONG", fused)
+            mesh = build()
+            with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-12, max_inner=400, check_every=1), control) as sm:
+                st = sm.iterate(2)
+                sm.download()
+            assert st["not_converged"] == 0
+            out.append((mesh_flat(mesh), st["inner_iterations"]))
+        assert out[0][1] == out[1][1]
+        assert np.array_equal(out[0][0], out[1][0])
