@@ -1380,7 +1380,8 @@ struct VirtualDot {
 };
 // MINW = workgroups per CU the register allocation must allow.  VK_R needs ~290 registers: with room for two workgroups per CU it
 // spills 37-70 of them to scratch, which a small mesh (one round of workgroups, more of them than CUs) prefers to waiting for a
-// second round (T106: 28.0 against 29.7 us per iteration); a large mesh prefers no spills (4096^2: 874 against 890 us).
+// second round (T106: 28.0 against 29.7 us per iteration); a large mesh prefers no spills (4096^2: 874 against 890 us), and so does
+// a launch of at most one workgroup per CU (a 256^2 block: 20.7 against 22.1 us).
 template <bool HAS_PQ, int VK, int MINW>
 __global__ __launch_bounds__(256, MINW) void k_apply_vk(ApplyBatch B, int total_interior, EdgeRowsDev e, VirtualIn V, const double2* __restrict__ xk,
                                                   const double2* __restrict__ pq, double2* __restrict__ out, double* edge_partials, LazyScalars L) {
@@ -1503,7 +1504,7 @@ hipError_t launch_apply_virtual(const ApplyBlock* blocks, int n, const EdgeRowsD
             if (has_pq) TM_VK(true, VK_P);
             else TM_VK(false, VK_P);
         } else if (V.kind == VK_R) {
-            if (grid.x > 2048) {
+            if (grid.x > 2048 || grid.x <= 256) {   // large meshes; and launches of at most one workgroup per CU (nothing to fit beside it)
                 if (has_pq) TM_VK1(true, VK_R);
                 else TM_VK1(false, VK_R);
             } else {
