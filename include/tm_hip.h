@@ -131,7 +131,7 @@ enum {
 typedef struct tm_solver_opt {
     int32_t tag;             /* TM_SOLVER_* */
     int32_t inner;           /* TM_INNER_* */
-    double rtol;             /* stop the inner solve at ||D^-1(b-Ax)||_2 <= max(atol, rtol*||D^-1 b||_2); 0 -> 1e-12 */
+    double rtol;             /* stop the inner solve at ||D^-1(b-Ax)||_2 <= max(atol, rtol*||D^-1 b||_2); 0 -> 1e-14 */
     double atol;             /* 0 -> 0 */
     uint64_t max_inner;      /* BiCGStab iteration cap per Picard solve; 0 -> 1000 (BiCGStab.zig:19) */
     uint32_t check_every;    /* host convergence poll interval in inner iterations; 0 -> 8 (1 with the multigrid preconditioner) */

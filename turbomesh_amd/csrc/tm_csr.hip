@@ -143,7 +143,7 @@ extern "C" int tm_csr_solve(uint64_t n64, const int32_t* Ap, const int32_t* Ai, 
         tm_solver_opt opt;
         std::memset(&opt, 0, sizeof(opt));
         if (opt_in) opt = *opt_in;
-        if (!(opt.rtol > 0)) opt.rtol = 1e-12;
+        if (!(opt.rtol > 0)) opt.rtol = 1e-14;
         if (!(opt.atol > 0)) opt.atol = 0.0;
         if (opt.max_inner == 0) opt.max_inner = 1000;
         if (opt.check_every == 0) opt.check_every = 8;

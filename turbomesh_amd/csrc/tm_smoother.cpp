@@ -148,7 +148,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         throw TmError(TM_E_UNSUPPORTED, "ExternalSolverNotEnabled: libtm_hip serves only solver tag `hip` (gmres/bicgstab/umfpack/petsc stay on the Zig side)");
     if (o->inner != TM_INNER_BICGSTAB && o->inner != TM_INNER_RELAX && o->inner != TM_INNER_MG_BICGSTAB) throw TmError(TM_E_ARG, "unknown inner strategy");
     opt = *o;
-    if (!(opt.rtol > 0)) opt.rtol = 1e-12;
+    if (!(opt.rtol > 0)) opt.rtol = 1e-14;
     if (!(opt.atol > 0)) opt.atol = 0.0;
     if (opt.max_inner == 0) opt.max_inner = 1000;
     if (opt.check_every == 0) opt.check_every = (opt.inner == TM_INNER_MG_BICGSTAB) ? 1 : 8;   // a multigrid-preconditioned iteration costs ~100x a poll

@@ -42,7 +42,7 @@ class Option:
     tag: Tag = Tag.hip
     preconditioner: Preconditioner = Preconditioner.diagonal   # payload of gmres / bicgstab
     inner: Inner = Inner.bicgstab
-    rtol: float = 0.0          # 0 -> library default 1e-12 (scaled residual)
+    rtol: float = 0.0          # 0 -> library default 1e-14 (scaled residual)
     atol: float = 0.0
     max_inner: int = 0         # 0 -> 1000 (BiCGStab.zig:19)
     check_every: int = 0       # 0 -> 8
