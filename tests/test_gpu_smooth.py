@@ -281,3 +281,20 @@ def test_more_blocks_than_one_batch_launch_holds():
         assert st["not_converged"] == 0
         rms = float(np.sqrt(np.mean((mesh_flat(mesh) - om.flat()) ** 2)))
         assert rms <= 1e-10, (eager, rms)
+
+
+def test_default_tolerance_meets_the_parity_bar_on_stretched_cells():
+    # the worst case of tools/dev/fuzz_picard_topologies.py: 10 coupled blocks of 35 x 135 nodes (cell aspect ratio ~ 4 and a condition
+    # number of ~1e3 per unit of rtol).  With the library's DEFAULT options every Picard iterate must be within north_star's 1e-10
+    # RMS of the exact-solve oracle (1e-12 as the default tolerance left it at 2e-9).
+    build = lambda tfi=None: configs.strip(10, 35, 135, tfi=tfi)
+    om = OracleMesh(build(oracle_tfi))
+    _, iterates = oracle.picard_exact(om, 2, keep_iterates=True)
+    mesh = build()
+    with smooth.Smoother(mesh) as sm:
+        for it in range(2):
+            st = sm.iterate(1)
+            sm.download()
+            ref = np.concatenate([b.reshape(-1, 2) for b in iterates[it]], axis=0)
+            rms = float(np.sqrt(np.mean((mesh_flat(mesh) - ref) ** 2)))
+            assert st["not_converged"] == 0 and rms <= 1e-10, (it, rms)
