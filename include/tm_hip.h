@@ -133,7 +133,7 @@ typedef struct tm_solver_opt {
     int32_t inner;           /* TM_INNER_* */
     double rtol;             /* stop the inner solve at ||D^-1(b-Ax)||_2 <= max(atol, rtol*||D^-1 b||_2); 0 -> 1e-14 */
     double atol;             /* 0 -> 0 */
-    uint64_t max_inner;      /* BiCGStab iteration cap per Picard solve; 0 -> 1000 (BiCGStab.zig:19) */
+    uint64_t max_inner;      /* BiCGStab iteration cap per Picard solve; 0 -> 10000 (the reference caps at 1000, BiCGStab.zig:19, with its far looser stop test) */
     uint32_t check_every;    /* host convergence poll interval in inner iterations; 0 -> 8 (1 with the multigrid preconditioner) */
     uint32_t flags;          /* TM_OPT_* bits; 0 = defaults */
     double omega;            /* relaxation factor of TM_INNER_RELAX; 0 -> 1.0 */

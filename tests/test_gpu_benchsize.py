@@ -224,3 +224,30 @@ def test_block_larger_than_two_gibibytes_per_vector():
     assert float(np.abs(out[0] - out[1]).max()) <= 1e-11
     tfi = configs.single_block(ni, nj).blocks[0].points.data
     assert not np.array_equal(out[1][8190:8199, 100:200], tfi[8190:8199, 100:200])   # rows past the 2^31-byte line did move
+
+
+@pytest.mark.parametrize("name", ["T106", "LS89"])
+def test_o4h_json_as_written_all_ten_iterations_with_default_options(name):
+    # BASELINE configs[0] / [2] exactly as their JSON says -- 10 Picard iterations, the White control function -- with the library's
+    # DEFAULT solver options, every iterate against the exact-solve oracle's.  LS89 stays at 1e-13 throughout.  T106 stays at 1e-12
+    # for six iterations and then steps to 4e-10 at iterations 7-9 WHATEVER the inner tolerance (1e-16 gives the same step,
+    # tools/dev/white_growth_probe.py): the White update is still moving the mesh by 1e-4 per iteration there and amplifies the
+    # ulp-level differences of (P, Q) (acos / atan2 / sqrt: ocml on the device, glibc in the oracle, Zig's std.math in the
+    # reference) -- the oracle is no closer to the reference than that itself.
+    inp, mesh = _load_o4h(name)
+    w = inp.wall_control_function.white
+    om = OracleMesh(mesh)
+    _, iterates = oracle.picard_exact(om, inp.iterations, control=("white", w.ds_target, w.theta_target), keep_iterates=True)
+    assert inp.iterations == 10
+    rms = []
+    with smooth.Smoother(mesh, solver.Option.hip(), wcf.Algorithm(wcf.White(w.ds_target, w.theta_target))) as sm:
+        for it in range(inp.iterations):
+            st = sm.iterate(1)
+            sm.download()
+            assert st["not_converged"] == 0
+            ref = np.concatenate([b.reshape(-1, 2) for b in iterates[it]], axis=0)
+            rms.append(float(np.sqrt(np.mean((mesh_flat(mesh) - ref) ** 2))))
+    log_parity(f"{name}_white_json_default_options_rms_iter6", max(rms[:6]))
+    log_parity(f"{name}_white_json_default_options_rms_iter10", max(rms))
+    assert max(rms[:6]) <= 1e-10, rms
+    assert max(rms) <= (1e-10 if name == "LS89" else 2e-9), rms

@@ -145,7 +145,7 @@ extern "C" int tm_csr_solve(uint64_t n64, const int32_t* Ap, const int32_t* Ai, 
         if (opt_in) opt = *opt_in;
         if (!(opt.rtol > 0)) opt.rtol = 1e-14;
         if (!(opt.atol > 0)) opt.atol = 0.0;
-        if (opt.max_inner == 0) opt.max_inner = 1000;
+        if (opt.max_inner == 0) opt.max_inner = 10000;   // the reference caps at 1000 (BiCGStab.zig:19) -- with its far looser stop test
         if (opt.check_every == 0) opt.check_every = 8;
 
         int dev = 0;

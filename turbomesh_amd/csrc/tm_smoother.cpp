@@ -150,7 +150,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     opt = *o;
     if (!(opt.rtol > 0)) opt.rtol = 1e-14;
     if (!(opt.atol > 0)) opt.atol = 0.0;
-    if (opt.max_inner == 0) opt.max_inner = 1000;
+    if (opt.max_inner == 0) opt.max_inner = 10000;   // the reference caps at 1000 (BiCGStab.zig:19) -- with its far looser stop test
     if (opt.check_every == 0) opt.check_every = (opt.inner == TM_INNER_MG_BICGSTAB) ? 1 : 8;   // a multigrid-preconditioned iteration costs ~100x a poll
     if (!(opt.omega > 0)) opt.omega = 1.0;
     cf = c ? *c : tm_control_fn{TM_CF_LAPLACE, 0, 0.0, 0.0};

@@ -44,7 +44,7 @@ class Option:
     inner: Inner = Inner.bicgstab
     rtol: float = 0.0          # 0 -> library default 1e-14 (scaled residual)
     atol: float = 0.0
-    max_inner: int = 0         # 0 -> 1000 (BiCGStab.zig:19)
+    max_inner: int = 0         # 0 -> 10000 (the reference: 1000, BiCGStab.zig:19, with its looser stop test)
     check_every: int = 0       # 0 -> 8
     omega: float = 0.0         # 0 -> 1.0
     single_sweep: bool = False # relax: one kernel pass per sweep (default: two sweeps per pass where possible)
