@@ -2104,7 +2104,7 @@ hipError_t launch_xr_update(const LazyScalars& S, double2* u, const double2* p_h
     return hipGetLastError();
 }
 
-// k_xr_update with s = r - alpha v formed on the fly (it was never stored: k_apply_vin): r is read and written in place
+// k_xr_update with s = r - alpha v formed on the fly (it was never stored: k_apply_vk<VK_S>): r is read and written in place
 __global__ __launch_bounds__(VEC_BLOCK) void k_xr_update_vs(LazyScalars L, double2* __restrict__ u, const double2* __restrict__ p, const double2* __restrict__ v,
                                                             const double2* __restrict__ t, double2* __restrict__ r, const double2* __restrict__ r_hat, int64_t n,
                                                             double* partials) {
