@@ -482,3 +482,12 @@ def time_relax_sweeps(xy, sweeps, omega=1.0):
     scratch = np.empty_like(xy)
     return float(lib().orc_time_relax_sweeps(C.c_uint64(xy.shape[0]), C.c_uint64(xy.shape[1]), xy.ctypes.data_as(_dp),
                                              scratch.ctypes.data_as(_dp), C.c_uint64(sweeps), C.c_double(omega)))
+
+
+def ref_white_math(x, y):
+    """acos(x), atan2(y, x) with the reference's libm algorithm (orc_refmath.hpp) -> (acos, atan2) arrays."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.ascontiguousarray(y, dtype=np.float64)
+    a, t = np.empty_like(x), np.empty_like(x)
+    lib().orc_ref_white_math(x.ctypes.data_as(_dp), y.ctypes.data_as(_dp), C.c_uint64(x.size), a.ctypes.data_as(_dp), t.ctypes.data_as(_dp))
+    return a, t

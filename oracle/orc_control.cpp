@@ -2,6 +2,7 @@
 // Follows reference src/core/smoothing/wall_control_function.zig:22-474 (live code only;
 // KhamaysehEtAl :476-725 is dead code and not restated).  `white` is hard-coded to blocks
 // 0,1 and connection 0 of the O4H template exactly like the reference (:72, :204-213).
+#include "orc_refmath.hpp"   // the reference's libm (Zig std.math = musl's acos / atan2), not glibc's
 #include "orc_system.hpp"
 
 namespace orc {
@@ -115,11 +116,11 @@ void computeUpdate(const White& w, Index& local_id, std::vector<Vec2d>& cf, Floa
     const Float g12 = x_xi * x_eta + y_xi * y_eta;
     const Float g22 = x_eta * x_eta + y_eta * y_eta;
     const Float ds = std::sqrt(g22);
-    const Float theta = std::acos(g12 / std::sqrt(g11 * g22));
+    const Float theta = orc_refmath::acos(g12 / std::sqrt(g11 * g22));
     const Float delta_ds = w.ds_target - ds;
     const Float delta_theta = w.theta_target - theta;
-    const Float delta_p = -std::atan2(delta_theta, w.theta_target);
-    const Float delta_q = std::atan2(delta_ds, w.ds_target);
+    const Float delta_p = -orc_refmath::atan2(delta_theta, w.theta_target);
+    const Float delta_q = orc_refmath::atan2(delta_ds, w.ds_target);
     Float p = cf[block_range_start + local_id].data[0], q = cf[block_range_start + local_id].data[1];
     p += 0.1 * delta_p;
     q += 0.1 * delta_q;
@@ -172,9 +173,9 @@ void whiteUpdate(const White& w, std::vector<Vec2d>& cf, const Mesh& mesh) {
         const Float g12 = x_xi * x_eta + y_xi * y_eta;
         const Float g22 = x_eta * x_eta + y_eta * y_eta;
         const Float ds = std::sqrt(g22);
-        const Float theta = std::acos(g12 / std::sqrt(g11 * g22));
-        const Float delta_p = -std::atan2(w.theta_target - theta, w.theta_target);
-        const Float delta_q = std::atan2(w.ds_target - ds, w.ds_target);
+        const Float theta = orc_refmath::acos(g12 / std::sqrt(g11 * g22));
+        const Float delta_p = -orc_refmath::atan2(w.theta_target - theta, w.theta_target);
+        const Float delta_q = orc_refmath::atan2(w.ds_target - ds, w.ds_target);
         Float p = cf[0].data[0], q = cf[0].data[1];
         p += 0.1 * delta_p;
         q += 0.1 * delta_q;
@@ -199,3 +200,11 @@ void ControlFunction::update(const Mesh& mesh) {
 }
 
 }  // namespace orc
+
+
+extern "C" void orc_ref_white_math(const double* x, const double* y, uint64_t n, double* out_acos, double* out_atan2) {
+    for (uint64_t i = 0; i < n; ++i) {
+        out_acos[i] = orc_refmath::acos(x[i]);
+        out_atan2[i] = orc_refmath::atan2(y[i], x[i]);
+    }
+}

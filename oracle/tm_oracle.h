@@ -157,6 +157,10 @@ double orc_time_relax_sweeps(uint64_t ni, uint64_t nj, double* xy, double* scrat
 /* the same with every sweep's rows split over `threads` host threads (not the reference's behaviour: it is single-threaded) */
 double orc_time_relax_sweeps_mt(uint64_t ni, uint64_t nj, double* xy, double* scratch, uint64_t sweeps, double omega, uint32_t threads);
 
+/* the reference's libm for the White control function (orc_refmath.hpp: Zig std.math = musl): out_acos[i] = acos(x[i]),
+ * out_atan2[i] = atan2(y[i], x[i]) */
+void orc_ref_white_math(const double* x, const double* y, uint64_t n, double* out_acos, double* out_atan2);
+
 #ifdef __cplusplus
 }
 #endif

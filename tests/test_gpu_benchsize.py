@@ -168,8 +168,8 @@ def test_o4h_white_from_the_json_vs_exact_picard(name):
             worst = max(worst, rms)
         pq = sm.control_function()
     assert np.abs(pq).max() > 0
-    # north_star: 1e-10 RMS.  (P,Q) pass through acos/atan2/sqrt: glibc on the oracle side, ocml on the device, Zig's
-    # std.math in the reference -- ulp-level differences in (P,Q), see DESIGN.md section 2
+    # north_star: 1e-10 RMS.  (P,Q) pass through acos / atan2: both sides evaluate the reference's own algorithm (Zig std.math =
+    # musl's; tm_refmath.h / orc_refmath.hpp, bit-identical: tests/test_gpu_refmath.py), see DESIGN.md section 2
     assert worst <= 1e-10, worst
 
 
@@ -230,10 +230,10 @@ def test_block_larger_than_two_gibibytes_per_vector():
 def test_o4h_json_as_written_all_ten_iterations_with_default_options(name):
     # BASELINE configs[0] / [2] exactly as their JSON says -- 10 Picard iterations, the White control function -- with the library's
     # DEFAULT solver options, every iterate against the exact-solve oracle's.  LS89 stays at 1e-13 throughout.  T106 stays at 1e-12
-    # for six iterations and then steps to 4e-10 at iterations 7-9 WHATEVER the inner tolerance (1e-16 gives the same step,
-    # tools/dev/white_growth_probe.py): the White update is still moving the mesh by 1e-4 per iteration there and amplifies the
-    # ulp-level differences of (P, Q) (acos / atan2 / sqrt: ocml on the device, glibc in the oracle, Zig's std.math in the
-    # reference) -- the oracle is no closer to the reference than that itself.
+    # for six iterations and then steps to 3e-10 at iterations 7-9 WHATEVER the inner tolerance (1e-16 gives the same step) and with
+    # bit-identical acos / atan2 on both sides (tests/test_gpu_refmath.py): the White update is still moving that mesh by 1e-4 per
+    # iteration there and amplifies any difference at the 1e-13 level -- an iterative inner solve against the oracle's sparse LU --
+    # a hundredfold (tools/dev/white_growth_probe.py).
     inp, mesh = _load_o4h(name)
     w = inp.wall_control_function.white
     om = OracleMesh(mesh)

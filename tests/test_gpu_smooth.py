@@ -136,7 +136,7 @@ def test_white_control_function_picard():
         st = sm.iterate(4)
         sm.download()
         assert st["not_converged"] == 0
-    assert _rms(mesh_flat(mesh), om.flat()) <= 1e-10   # north_star's bar; P,Q pass through acos/atan2 (glibc vs ocml: ulp-level)
+    assert _rms(mesh_flat(mesh), om.flat()) <= 1e-10   # north_star's bar; acos / atan2 of (P,Q): the reference's algorithm on both sides (tests/test_gpu_refmath.py)
 
 
 def test_full_size_sweep_properties():

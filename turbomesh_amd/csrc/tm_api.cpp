@@ -83,6 +83,23 @@ int tm_diag_apply(const double* d_in, double* d_out, uint64_t ni, uint64_t nj, i
 }
 
 // ------------------------------------------------------------------ TFI (tfi.zig:112-208)
+// internal (tests/test_gpu_refmath.py): acos(x[i]) and atan2(y[i], x[i]) as the device's White kernels evaluate them (tm_refmath.h),
+// host arrays in and out.  Not part of the drop-in surface.
+int tm_debug_white_math(const double* x, const double* y, uint64_t n, double* out_acos, double* out_atan2) {
+    return guarded([&]() {
+        if (!x || !y || !out_acos || !out_atan2) throw TmError(TM_E_ARG, "null argument");
+        require_gfx950();
+        const size_t nb = sizeof(double) * n;
+        DevBuf dx(nb), dy(nb), da(nb), dt(nb);
+        HIPCHK(hipMemcpy(dx.p, x, nb, hipMemcpyHostToDevice));
+        HIPCHK(hipMemcpy(dy.p, y, nb, hipMemcpyHostToDevice));
+        HIPCHK(launch_debug_white_math(dx.as<double>(), dy.as<double>(), n, da.as<double>(), dt.as<double>(), nullptr));
+        HIPCHK(hipMemcpy(out_acos, da.p, nb, hipMemcpyDeviceToHost));
+        HIPCHK(hipMemcpy(out_atan2, dt.p, nb, hipMemcpyDeviceToHost));
+        return TM_OK;
+    });
+}
+
 int tm_tfi_block(double* xy_out, uint64_t ni, uint64_t nj, const double* x_i_min, const double* x_i_max, const double* x_j_min,
                  const double* x_j_max, const double* s1, const double* s2, const double* t1, const double* t2) {
     return guarded([&]() {

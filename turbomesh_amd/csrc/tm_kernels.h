@@ -301,4 +301,7 @@ hipError_t launch_mg_scale(const double2* f, double2* out, int ni, int nj, doubl
 // ---- K8 export: interleaved (i*nj + j) block -> two planes with i fastest (cgns.zig:75-104)
 hipError_t launch_soa_planes(const double2* in, double* plane0, double* plane1, int ni, int nj, hipStream_t stream);
 
+// test hook: acos(x[i]) and atan2(y[i], x[i]) with the device build of tm_refmath.h (device pointers)
+hipError_t launch_debug_white_math(const double* x, const double* y, uint64_t n, double* out_acos, double* out_atan2, hipStream_t stream);
+
 }  // namespace tmh

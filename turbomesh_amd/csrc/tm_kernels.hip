@@ -26,6 +26,7 @@
 // (row-chunk, strip) tiles: the halo lines shared by neighbouring tiles hit in that L2.
 #include "tm_kernels.h"
 #include "tm_devutil.hpp"
+#include "tm_refmath.h"
 #include <cstdlib>
 #include <type_traits>
 
@@ -2358,10 +2359,10 @@ __device__ __forceinline__ double2 white_delta(double x_xi, double y_xi, double 
     const double g12 = x_xi * x_eta + y_xi * y_eta;
     const double g22 = x_eta * x_eta + y_eta * y_eta;
     const double ds = sqrt(g22);
-    const double theta = acos(g12 / sqrt(g11 * g22));
+    const double theta = tm_refmath::acos(g12 / sqrt(g11 * g22));   // the reference's libm, not ocml's (tm_refmath.h)
     const double delta_ds = ds_target - ds;
     const double delta_theta = theta_target - theta;
-    return make_double2(-atan2(delta_theta, theta_target), atan2(delta_ds, ds_target));
+    return make_double2(-tm_refmath::atan2(delta_theta, theta_target), tm_refmath::atan2(delta_ds, ds_target));
 }
 
 __global__ void k_white_wall(const double2* __restrict__ d, double2* __restrict__ pq, int ni, int nj, int update, double ds_target,
@@ -2445,6 +2446,21 @@ hipError_t launch_white(const WhiteArgs& w, int update, hipStream_t st) {
     hipLaunchKernelGGL(k_white_le, dim3(1), dim3(64), 0, st, w, update);
     hipLaunchKernelGGL(k_white_blend, dim3((w.nj0 + 63) / 64, w.ni0), dim3(64), 0, st, w.pq0, w.ni0, w.nj0);
     hipLaunchKernelGGL(k_white_blend, dim3((w.nj1 + 63) / 64, w.ni1), dim3(64), 0, st, w.pq1, w.ni1, w.nj1);
+    return hipGetLastError();
+}
+
+
+// test hook (tm_debug_white_math): the two libm functions of the White control function, evaluated on the device
+__global__ __launch_bounds__(256) void k_debug_white_math(const double* __restrict__ x, const double* __restrict__ y, uint64_t n, double* __restrict__ out_acos,
+                                                          double* __restrict__ out_atan2) {
+    const uint64_t i = blockIdx.x * 256ull + threadIdx.x;
+    if (i >= n) return;
+    out_acos[i] = tm_refmath::acos(x[i]);
+    out_atan2[i] = tm_refmath::atan2(y[i], x[i]);
+}
+hipError_t launch_debug_white_math(const double* x, const double* y, uint64_t n, double* out_acos, double* out_atan2, hipStream_t st) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_debug_white_math, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, x, y, n, out_acos, out_atan2);
     return hipGetLastError();
 }
 
