@@ -75,7 +75,7 @@ def test_hip_smoothing_matches_golden(path):
     z = np.load(path)
     mesh, control = load_mesh(z)
     algo = wcf.Algorithm.laplace() if control is None else wcf.Algorithm(wcf.White(control[1], control[2]))
-    tol = 1e-10   # north_star's bar, also with the white control function (fixtures generated with glibc's acos / atan2, the code under test uses the reference's algorithm: ulp-level in (P,Q))
+    tol = 1e-10   # north_star's bar, also with the white control function (acos / atan2 of (P,Q): the reference's algorithm in the fixtures' generator and on the device)
     with smooth.Smoother(mesh, solver.Option.hip(rtol=1e-13, max_inner=5000), algo) as sm:
         for k in range(len(z["residual_history"])):
             st = sm.iterate(1)
