@@ -38,12 +38,12 @@ for k in range(cases):
     om = OracleMesh(build(oracle_tfi))
     oracle.picard_exact(om, 2, control=("white", 0.02, np.pi / 2) if control else None)
     mesh = build()
-    with smooth.Smoother(mesh, solver.Option.hip(rtol=1e-13, max_inner=20000), control) as sm:
+    with smooth.Smoother(mesh, solver.Option.hip(), control) as sm:   # the library's defaults
         st = sm.iterate(2)
         sm.download()
     rms = float(np.sqrt(np.mean((mesh_flat(mesh) - om.flat()) ** 2)))
     worst_exact = max(worst_exact, rms)
-    assert st["not_converged"] == 0 and rms <= 2e-9, (name, rms, st)
+    assert st["not_converged"] == 0 and rms <= 1e-10, (name, rms, st)   # north_star's bar
     pair = []
     for eager in (True, False):
         m = build()
