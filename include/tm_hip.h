@@ -131,9 +131,9 @@ enum {
 typedef struct tm_solver_opt {
     int32_t tag;             /* TM_SOLVER_* */
     int32_t inner;           /* TM_INNER_* */
-    double rtol;             /* stop the inner solve at ||D^-1(b-Ax)||_2 <= max(atol, rtol*||D^-1 b||_2); 0 -> 1e-14 */
+    double rtol;             /* stop the inner solve at ||D^-1(b-Ax)||_2 <= max(atol, rtol*||D^-1 b||_2); 0 -> size-aware default: 7.5e-9 / nodes clamped to [1e-16, 1e-14] (1e-14 up to 866^2 nodes; the error of the solve is conditioning x residual and the conditioning grows with the mesh) */
     double atol;             /* 0 -> 0 */
-    uint64_t max_inner;      /* BiCGStab iteration cap per Picard solve; 0 -> 10000 (the reference caps at 1000, BiCGStab.zig:19, with its far looser stop test) */
+    uint64_t max_inner;      /* BiCGStab iteration cap per Picard solve; 0 -> max(10000, 12 sqrt(nodes)) (the reference caps at 1000, BiCGStab.zig:19, with its far looser stop test) */
     uint32_t check_every;    /* host convergence poll interval in inner iterations; 0 -> 8 (1 with the multigrid preconditioner) */
     uint32_t flags;          /* TM_OPT_* bits; 0 = defaults */
     double omega;            /* relaxation factor of TM_INNER_RELAX; 0 -> 1.0 */
@@ -233,6 +233,10 @@ int tm_smoother_iterate(tm_smoother* s, uint64_t iterations, tm_stats* stats);
  * smooth.zig:104; it has no stop test).  TM_OK = reached; TM_W_NOT_CONVERGED = max_iterations hit or an inner solve did not
  * converge.  stats->outer_iterations = iterations actually performed (Picard: solves; relax: sweeps, tested every 32). */
 int tm_smoother_iterate_until(tm_smoother* s, uint64_t max_iterations, double scaled_residual_tol, tm_stats* stats);
+/* ... until the update of the last outer iteration, sqrt((sum dx^2 + sum dy^2) / nodes) over the whole mesh, is <= update_rms_tol:
+ * the quantity the reference forms and logs per iteration (smooth.zig:112-137) -- convergence of the COORDINATES.  Returns
+ * TM_W_NOT_CONVERGED when max_iterations ran out first (stats are valid either way). */
+int tm_smoother_iterate_until_update(tm_smoother* s, uint64_t max_iterations, double update_rms_tol, tm_stats* stats);
 int tm_smoother_download(tm_smoother* s, const tm_mesh_desc* mesh);
 int tm_smoother_upload(tm_smoother* s, const tm_mesh_desc* mesh);
 void tm_smoother_destroy(tm_smoother* s);
@@ -250,6 +254,20 @@ int tm_rccl_unique_id(const char* librccl_path, void* id_out /* TM_RCCL_ID_BYTES
 int tm_rccl_comm_create(const char* librccl_path, const void* id, int32_t rank, int32_t nranks, tm_rccl_comm** out);
 void tm_rccl_comm_destroy(tm_rccl_comm* comm);
 int tm_rccl_hooks(tm_rccl_comm* comm, const tm_mesh_desc* mesh, const int32_t* owner /* [nblocks] */, tm_comm_hooks* hooks);
+
+/* The table tm_rccl_hooks builds for a rank, host-only (no communicator, no GPU): per neighbouring rank the offset and count
+ * (rows of 16 B) handed to ncclSend / ncclRecv in one group per exchange.  Pairwise symmetry -- send_cnt of a towards b ==
+ * recv_cnt of b from a, peers mutual, offsets inside send_rows / recv_rows -- is what keeps ncclGroupEnd from hanging; a caller
+ * (or a test) can check it for every rank of a partition before any process joins a communicator.
+ * send_off indexes the rank's own vector when direct_send (n_owned + n_ghost rows), the packed send buffer otherwise. */
+typedef struct tm_rccl_peer_table {
+    int32_t npeers, direct_send;
+    int64_t send_rows, recv_rows;   /* extent of the buffers the offsets index */
+    int32_t* peer;                  /* [npeers] ascending                      */
+    int64_t *send_off, *send_cnt, *recv_off, *recv_cnt;   /* [npeers] each      */
+} tm_rccl_peer_table;
+int tm_rccl_peer_table_build(const tm_mesh_desc* mesh, const int32_t* owner, int32_t rank, int32_t nranks, tm_rccl_peer_table* out);
+void tm_rccl_peer_table_free(tm_rccl_peer_table* table);
 
 /* Exchange plan of a handle created with hooks: npeers peers; for peer k, send_count[k] rows
  * (16 B each) start at send_offset[k] rows into send_buf, same for recv.  Rows are double2.
@@ -338,6 +356,10 @@ typedef struct tm_plan_local_info {
 } tm_plan_local_info;
 int tm_plan_local(const tm_mesh_desc* mesh, const int32_t* owner, int32_t rank, int32_t nranks, tm_plan_local_info* out);
 void tm_plan_local_free(tm_plan_local_info* info);
+
+/* Diagnostic: acos(x[i]) and atan2(y[i], x[i]) exactly as the White kernels evaluate them on the device (csrc/tm_refmath.h: the
+ * reference's libm algorithm, Zig std.math = musl's, wall_control_function.zig:298-308).  Host arrays in and out. */
+int tm_white_math_probe(const double* x, const double* y, uint64_t n, double* out_acos, double* out_atan2);
 
 /* ------------------------------------------------------------------ device-level entry points
  * Same kernels on caller-provided DEVICE pointers and stream, for callers that keep blocks in

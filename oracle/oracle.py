@@ -379,10 +379,14 @@ class System:
         return float(r), dx2.value, dy2.value
 
 
-def picard_exact(mesh, iterations, control=None, keep_iterates=False):
+def picard_exact(mesh, iterations, control=None, keep_iterates=False, permc_spec="COLAMD"):
     """Exact Picard iteration = the reference with its UMFPACK backend (umfpack.zig:18-24):
     oracle-assembled CSR, each component solved by an independent sparse LU (scipy splu).
-    Mutates mesh.blocks in place.  Returns (residual_history, iterates|None)."""
+    Mutates mesh.blocks in place.  Returns (residual_history, iterates|None).
+    permc_spec: SuperLU's column ordering -- a different elimination order is a different exact solver in floating point; the
+    distance between two of them is the floor any comparison with "the exact iterate" can be held to
+    (tests/test_oracle_self_distance.py).  When fillYSpecific leaves the values as fillXSpecific did (no sliding rows) the x
+    factorisation serves the y system as well -- the same arithmetic as factorising it again."""
     import scipy.sparse.linalg as spla
 
     s = System(mesh, control)
@@ -390,11 +394,31 @@ def picard_exact(mesh, iterations, control=None, keep_iterates=False):
     for n in range(iterations):
         s.fill(n)
         s.fill_x_specific()
-        x = spla.splu(s.csr().tocsc()).solve(s.rhs_x.copy())
+        vx = s.lhs_values.copy()
+        lu = spla.splu(s.csr().tocsc(), permc_spec=permc_spec)
+        x = lu.solve(s.rhs_x.copy())
         s.fill_y_specific()
-        y = spla.splu(s.csr().tocsc()).solve(s.rhs_y.copy())
+        if not np.array_equal(vx, s.lhs_values):
+            lu = spla.splu(s.csr().tocsc(), permc_spec=permc_spec)
+        y = lu.solve(s.rhs_y.copy())
+        del lu
         s.x_new[:] = x
         s.y_new[:] = y
+        hist.append(s.commit()[0])
+        if keep_iterates:
+            iterates.append([b.copy() for b in mesh.blocks])
+    s.close()
+    return np.array(hist), (iterates if keep_iterates else None)
+
+
+def picard_direct(mesh, iterations, control=None, keep_iterates=False):
+    """The same Picard iteration with the oracle's own banded LU (orc_solvers.cpp, partial pivoting inside the band) as the
+    exact solver -- a third elimination order, for meshes whose bandwidth it can hold (single blocks, strips)."""
+    s = System(mesh, control)
+    hist, iterates = [], []
+    for n in range(iterations):
+        s.fill(n)
+        s.solve(SOLVER_DIRECT)
         hist.append(s.commit()[0])
         if keep_iterates:
             iterates.append([b.copy() for b in mesh.blocks])

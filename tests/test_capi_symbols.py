@@ -27,6 +27,18 @@ def test_header_symbols_exported():
     assert sorted(set(_capi.EXPORTS)) == declared, set(declared) ^ set(_capi.EXPORTS)
 
 
+def test_product_library_exports_nothing_the_header_does_not_declare():
+    # the measurement helpers (tm_debug_*, tm_tune_*, tm_diag_*) live in libtm_hip_dbg.so only (csrc/Makefile, -DTM_DEBUG_EXPORTS)
+    import subprocess
+
+    out = subprocess.run(["nm", "-D", "--defined-only", _capi.LIB_PATH], capture_output=True, text=True, check=True).stdout
+    exported = sorted({ln.split()[-1] for ln in out.splitlines() if ln.split() and ln.split()[-1].startswith("tm_")})
+    assert exported == _declared_functions(), set(exported) ^ set(_declared_functions())
+    if os.path.exists(_capi.DBG_LIB_PATH):
+        dbg = ctypes.CDLL(_capi.DBG_LIB_PATH)
+        assert all(hasattr(dbg, n) for n in _declared_functions() + ["tm_debug_null_hooks", "tm_tune_apply", "tm_diag_apply"])
+
+
 def test_abi_version_and_error_string_without_gpu():
     lib = _capi.lib()
     assert lib.tm_abi_version() == 1

@@ -1,0 +1,146 @@
+"""Picard parity up the size ladder: is "every Picard iterate within 1e-10 RMS of the exact-solve iterate" still
+true where the conditioning of the frozen system (~ n^2) bites?
+
+Each case: a perturbed block (interior nodes displaced by 0.25 h, SURVEY 8d config 2's convergence variant) or a roughened 2-block
+strip, TWO Picard iterates (smooth.zig:104-154) through the GPU's `bicgstab` (the reference's inner solver, BiCGStab.zig:279-370, on
+D^-1 A, matrix-free) and `mg_bicgstab` with the library's DEFAULT options, against the reference run with an exact linear solve
+(its UMFPACK backend, umfpack.zig:18-24 = oracle-assembled CSR + scipy splu).  Beside it the oracle's distance from ITSELF with a
+second elimination order -- the fp64 floor of "the exact iterate" at that size.  Every figure goes to gpurun_out/parity_rms.log;
+the table in DESIGN.md section 5 is that log.  Measured on the MI355X box (round 3):
+
+      n     floor (splu vs splu)   bicgstab, rtol 1e-14   mg_bicgstab
+     129         8e-15                  5e-13                9e-15
+     257         1e-14                  7e-12                2e-14
+     513         5e-14                  2e-11                5e-14
+    1025         2e-13                  2e-11                4e-13
+"""
+import time
+
+import numpy as np
+import pytest
+
+from oracle import oracle
+from tests.conftest import OracleMesh, mesh_flat
+from tests.test_gpu_benchsize import log_parity
+from turbomesh_amd import configs
+from turbomesh_amd.smoothing import smooth, solver
+
+pytestmark = pytest.mark.gpu
+TOL_RMS = 1e-10   # BASELINE.json north_star, fp64
+
+
+def _rms(a, b):
+    return float(np.sqrt(np.mean((a - b) ** 2)))
+
+
+def _flat(iterates):
+    return [np.concatenate([b.reshape(-1, 2) for b in it], axis=0) for it in iterates]
+
+
+def _rough_strip(n):
+    m = configs.strip(2, n, n)
+    rng = np.random.default_rng(7)
+    for b in m.blocks:   # interior nodes only: the two copies of the interface stay matched (connectionDataCheck, smooth.zig:220-275)
+        d = b.points.data
+        d[1:-1, 1:-1] += 0.25 / (n - 1) * (rng.random(d[1:-1, 1:-1].shape) - 0.5)
+    return m
+
+
+CASES = {
+    "block257": lambda: configs.single_block(257, 257, perturb=0.25),
+    "block513": lambda: configs.single_block(513, 513, perturb=0.25),
+    "block1025": lambda: configs.single_block(1025, 1025, perturb=0.25),
+    "strip2x513": lambda: _rough_strip(513),
+}
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_two_picard_iterates_vs_exact_solve(name):
+    build = CASES[name]
+    seed = build()
+    t0 = time.time()
+    ref = _flat(oracle.picard_exact(OracleMesh(seed), 2, keep_iterates=True)[1])
+    alt = _flat(oracle.picard_exact(OracleMesh(seed), 2, keep_iterates=True, permc_spec="MMD_AT_PLUS_A")[1])
+    floor = max(_rms(a, b) for a, b in zip(ref, alt))
+    log_parity(f"ladder_{name}_oracle_floor", floor)
+    print(f"[ladder] {name}: two sparse LUs in {time.time() - t0:.0f} s, floor {floor:.1e}; first step moves {_rms(ref[0], mesh_flat(seed)):.1e}")
+    assert floor <= 1e-11, floor      # the yardstick itself is good to two orders below the bar at these sizes
+    for inner in (solver.Inner.bicgstab, solver.Inner.mg_bicgstab):
+        mesh = build()
+        worst = 0.0
+        with smooth.Smoother(mesh, solver.Option.hip(inner=inner, max_inner=100000)) as sm:   # default rtol (1e-14), default everything
+            for k in range(2):
+                st = sm.iterate(1)
+                sm.download()
+                assert st["not_converged"] == 0, (name, inner.name, st)
+                worst = max(worst, _rms(mesh_flat(mesh), ref[k]))
+        log_parity(f"ladder_{name}_{inner.name}_rms", worst)
+        assert worst <= TOL_RMS, (name, inner.name, worst)
+        if inner == solver.Inner.mg_bicgstab:   # a preconditioner that makes the conditioning O(1) lands on the floor itself
+            assert worst <= max(20.0 * floor, 1e-12), (name, worst, floor)
+
+
+def test_default_tolerance_is_size_aware():
+    # csrc/tm_smoother.hpp default_rtol / default_max_inner: 1e-14 up to 866^2 nodes, then 7.5e-9 / nodes, never below 1e-16 --
+    # observable through the iteration counts of the same solve with rtol = 0 and with the value spelled out
+    n = 1400
+    a, b = configs.single_block(n, n, perturb=0.25), configs.single_block(n, n, perturb=0.25)
+    with smooth.Smoother(a) as sm:
+        sa = sm.iterate(1)
+        sm.download()
+    with smooth.Smoother(b, solver.Option.hip(rtol=7.5e-9 / (n * n), max_inner=int(12 * n))) as sm:
+        sb = sm.iterate(1)
+        sm.download()
+    assert sa["inner_iterations"] == sb["inner_iterations"] and sa["not_converged"] == 0
+    assert np.array_equal(a.blocks[0].points.data, b.blocks[0].points.data)
+
+
+def test_4096_two_routes_to_the_same_picard_iterates():
+    # BASELINE configs[1] at its full size, the reference's algorithm (Picard + linear solve, smooth.zig:104-154).  No sparse LU
+    # holds 16.7 M unknowns, so the two GPU routes check each other: `mg_bicgstab` (8 inner iterations per solve) against
+    # `bicgstab` with the diagonal alone (~18 000), both with DEFAULT options.  They share the operator kernels and the Krylov
+    # recurrences but nothing of what decides the error -- the spectrum each leaves in its final residual -- and each is tied to
+    # the sparse-LU oracle up to 2049^2 (1025^2 in the test above, 2049^2: tools/dev/picard_ladder.py).
+    # Fixed boundary bit-exact; the Picard update decreases.
+    n = 4096
+    seed = configs.single_block(n, n, perturb=0.25)
+    x0 = seed.blocks[0].points.data.copy()
+    del seed
+    out = {}
+    for inner, iters in ((solver.Inner.mg_bicgstab, 3), (solver.Inner.bicgstab, 1)):
+        mesh = configs.single_block(n, n, perturb=0.25)
+        its, upd = [], []
+        with smooth.Smoother(mesh, solver.Option.hip(inner=inner)) as sm:
+            for k in range(iters):
+                st = sm.iterate(1)
+                sm.download()
+                assert st["not_converged"] == 0, (inner.name, st)
+                its.append(mesh.blocks[0].points.data.copy())
+                upd.append(float(np.sqrt((st["last_dx2"] + st["last_dy2"]) / (n * n))))
+                print(f"[4096] {inner.name} iterate {k + 1}: inner {st['inner_iterations']}, update rms {upd[-1]:.2e}, {st['seconds']:.2f} s")
+        out[inner] = (its, upd)
+        d = its[-1]
+        assert np.array_equal(d[0], x0[0]) and np.array_equal(d[-1], x0[-1]) and np.array_equal(d[:, 0], x0[:, 0]) and np.array_equal(d[:, -1], x0[:, -1])
+    mg_its, mg_upd = out[solver.Inner.mg_bicgstab]
+    assert mg_upd[0] > mg_upd[1] > mg_upd[2], mg_upd
+    rms = _rms(mg_its[0], out[solver.Inner.bicgstab][0][0])
+    log_parity("ladder_block4096_mg_vs_bicgstab_default_options_rms", rms)
+    assert rms <= TOL_RMS, rms
+
+
+def test_1025_both_routes_reach_the_same_fixed_point():
+    # Picard run to convergence of the COORDINATES -- the update of the last iteration, the reference's own per-iteration quantity
+    # (smooth.zig:112-137), <= 1e-11 RMS -- through both inner solvers: same fixed point to 1e-10 RMS
+    n = 1025
+    res = []
+    for inner in (solver.Inner.mg_bicgstab, solver.Inner.bicgstab):
+        mesh = configs.single_block(n, n, perturb=0.25)
+        with smooth.Smoother(mesh, solver.Option.hip(inner=inner)) as sm:
+            reached, st = sm.iterate_until_update(1e-11, 60)
+            sm.download()
+        assert reached, st
+        print(f"[1025 fixed point] {inner.name}: {st['outer_iterations']} Picard iterations, {st['inner_iterations']} inner, {st['seconds']:.2f} s")
+        res.append(mesh.blocks[0].points.data.copy())
+    rms = _rms(res[0], res[1])
+    log_parity("ladder_block1025_fixed_point_mg_vs_bicgstab_rms", rms)
+    assert rms <= TOL_RMS, rms

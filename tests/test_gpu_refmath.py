@@ -51,14 +51,14 @@ def test_device_and_oracle_refmath_agree_bit_for_bit():
 
     L = _capi.lib()
     dp = C.POINTER(C.c_double)
-    L.tm_debug_white_math.argtypes = [dp, dp, C.c_uint64, dp, dp]
-    L.tm_debug_white_math.restype = C.c_int
+    L.tm_white_math_probe.argtypes = [dp, dp, C.c_uint64, dp, dp]
+    L.tm_white_math_probe.restype = C.c_int
     x, y, xs = _inputs()
     for xin in (x, xs):
         xin = np.ascontiguousarray(xin)
         a = np.empty_like(xin)
         t = np.empty_like(xin)
-        _capi.check(L.tm_debug_white_math(xin.ctypes.data_as(dp), y.ctypes.data_as(dp), xin.size, a.ctypes.data_as(dp), t.ctypes.data_as(dp)))
+        _capi.check(L.tm_white_math_probe(xin.ctypes.data_as(dp), y.ctypes.data_as(dp), xin.size, a.ctypes.data_as(dp), t.ctypes.data_as(dp)))
         ra, rt = oracle.ref_white_math(xin, y)
         assert np.array_equal(a.view(np.uint64)[~np.isnan(ra)], ra.view(np.uint64)[~np.isnan(ra)])
         assert np.array_equal(np.isnan(a), np.isnan(ra))

@@ -4,6 +4,7 @@
 three-part K2x2 launch and the hook calls add to the single-rank pass."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+os.environ.setdefault("TM_HIP_LIB", os.path.join(sys.path[0], "turbomesh_amd", "libtm_hip_dbg.so"))   # measurement build: tm_debug_* / tm_tune_* / tm_diag_*
 import torch
 from turbomesh_amd import distributed as tmd
 from turbomesh_amd.smoothing import solver

@@ -7,6 +7,7 @@ import time
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
+os.environ.setdefault("TM_HIP_LIB", os.path.join(ROOT, "turbomesh_amd", "libtm_hip_dbg.so"))   # measurement build: tm_debug_* / tm_tune_* / tm_diag_*
 from turbomesh_amd.input import Input
 from turbomesh_amd.smoothing import smooth, solver, wall_control_function as wcf
 

@@ -2,6 +2,7 @@
 """Device-side and host-side cost of the library's grouped ncclSend/ncclRecv exchange, with the own rank as the only peer."""
 import ctypes as C, os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+os.environ.setdefault("TM_HIP_LIB", os.path.join(sys.path[0], "turbomesh_amd", "libtm_hip_dbg.so"))   # measurement build: tm_debug_* / tm_tune_* / tm_diag_*
 import torch
 from turbomesh_amd import _capi
 L = _capi.lib()

@@ -13,6 +13,7 @@ import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("TM_HIP_LIB") or os.path.join(_HERE, "libtm_hip.so")   # TM_HIP_LIB: experiment builds only
+DBG_LIB_PATH = os.path.join(_HERE, "libtm_hip_dbg.so")   # the same library + the tm_debug_* / tm_tune_* / tm_diag_* helpers of tools/
 
 # tm_error
 TM_OK, TM_W_NOT_CONVERGED = 0, 1
@@ -102,13 +103,20 @@ class tm_plan_local_info(C.Structure):
                 ("ghost_row_cols", C.POINTER(C.c_int64))]
 
 
+class tm_rccl_peer_table(C.Structure):
+    _fields_ = [("npeers", C.c_int32), ("direct_send", C.c_int32), ("send_rows", C.c_int64), ("recv_rows", C.c_int64),
+                ("peer", C.POINTER(C.c_int32)), ("send_off", C.POINTER(C.c_int64)), ("send_cnt", C.POINTER(C.c_int64)),
+                ("recv_off", C.POINTER(C.c_int64)), ("recv_cnt", C.POINTER(C.c_int64))]
+
+
 # every symbol include/tm_hip.h declares (checked by tests/test_capi_symbols.py)
 EXPORTS = [
     "tm_last_error", "tm_abi_version", "tm_set_log", "tm_csr_solve", "tm_tfi_block", "tm_tfi_linear2d", "tm_smooth_mesh", "tm_smoother_create",
-    "tm_smoother_workspace_bytes", "tm_smoother_iterate", "tm_smoother_iterate_until", "tm_smoother_download", "tm_smoother_upload", "tm_smoother_destroy",
+    "tm_smoother_workspace_bytes", "tm_smoother_iterate", "tm_smoother_iterate_until", "tm_smoother_iterate_until_update", "tm_smoother_download", "tm_smoother_upload", "tm_smoother_destroy",
     "tm_smoother_exchange_plan", "tm_smoother_apply", "tm_smoother_rhs", "tm_smoother_row_kinds", "tm_smoother_dof",
     "tm_smoother_control_function", "tm_smoother_profile", "tm_smoother_profile_read", "tm_plan_build", "tm_plan_free", "tm_plan_local", "tm_plan_local_free", "tm_dev_tfi_block", "tm_dev_relax_sweep",
     "tm_dev_relax_partials_needed", "tm_export_soa", "tm_smoother_export_soa", "tm_rccl_unique_id", "tm_rccl_comm_create", "tm_rccl_comm_destroy", "tm_rccl_hooks",
+    "tm_rccl_peer_table_build", "tm_rccl_peer_table_free", "tm_white_math_probe",
 ]
 
 _lib = None
@@ -165,6 +173,7 @@ def lib():
                                                   C.POINTER(tm_comm_hooks), C.POINTER(C.c_uint64)]
         L.tm_smoother_iterate.argtypes = [C.c_void_p, C.c_uint64, C.POINTER(tm_stats)]
         L.tm_smoother_iterate_until.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.POINTER(tm_stats)]
+        L.tm_smoother_iterate_until_update.argtypes = [C.c_void_p, C.c_uint64, C.c_double, C.POINTER(tm_stats)]
         L.tm_smoother_download.argtypes = [C.c_void_p, C.POINTER(tm_mesh_desc)]
         L.tm_smoother_upload.argtypes = [C.c_void_p, C.POINTER(tm_mesh_desc)]
         L.tm_smoother_destroy.argtypes = [C.c_void_p]
@@ -185,7 +194,6 @@ def lib():
         L.tm_rccl_comm_create.argtypes = [C.c_char_p, C.c_void_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
         L.tm_rccl_comm_destroy.argtypes = [C.c_void_p]
         L.tm_rccl_comm_destroy.restype = None
-        L.tm_debug_null_hooks.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(tm_comm_hooks)]
         L.tm_rccl_hooks.argtypes = [C.c_void_p, C.POINTER(tm_mesh_desc), C.POINTER(C.c_int32), C.POINTER(tm_comm_hooks)]
         L.tm_plan_local.argtypes = [C.POINTER(tm_mesh_desc), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(tm_plan_local_info)]
         L.tm_plan_local_free.argtypes = [C.POINTER(tm_plan_local_info)]
@@ -193,9 +201,15 @@ def lib():
         L.tm_dev_tfi_block.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64] + [C.c_void_p] * 8 + [C.c_void_p]
         L.tm_dev_relax_sweep.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_double, C.c_void_p, C.c_uint64,
                                          C.POINTER(C.c_uint64), C.c_void_p]
-        L.tm_diag_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
-        L.tm_tune_fuse.argtypes = [C.c_int]
-        L.tm_tune_apply.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
+        L.tm_rccl_peer_table_build.argtypes = [C.POINTER(tm_mesh_desc), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(tm_rccl_peer_table)]
+        L.tm_rccl_peer_table_free.argtypes = [C.POINTER(tm_rccl_peer_table)]
+        L.tm_rccl_peer_table_free.restype = None
+        L.tm_white_math_probe.argtypes = [_dp, _dp, C.c_uint64, _dp, _dp]
+        if hasattr(L, "tm_tune_apply"):   # measurement build (TM_HIP_LIB=.../libtm_hip_dbg.so, tools/)
+            L.tm_debug_null_hooks.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(tm_comm_hooks)]
+            L.tm_diag_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]
+            L.tm_tune_fuse.argtypes = [C.c_int]
+            L.tm_tune_apply.argtypes = [C.c_int, C.c_int, C.c_int, C.c_int]
         _lib = L
     return _lib
 

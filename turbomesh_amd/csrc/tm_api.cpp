@@ -54,6 +54,7 @@ void tm_set_log(tm_log_fn sink, void* ctx) {
     g_log_ctx = ctx;
 }
 
+#ifdef TM_DEBUG_EXPORTS   // measurement build only (libtm_hip_dbg.so, tools/): not in include/tm_hip.h
 // internal tuning knob used by the benchmark sweeps (not part of the drop-in surface)
 int tm_tune_apply(int rows_per_chunk, int unroll, int pipe, int nt) {
     tune_apply(rows_per_chunk, unroll, pipe, nt);
@@ -81,11 +82,12 @@ int tm_diag_apply(const double* d_in, double* d_out, uint64_t ni, uint64_t nj, i
         return TM_OK;
     });
 }
+#endif   // TM_DEBUG_EXPORTS
 
 // ------------------------------------------------------------------ TFI (tfi.zig:112-208)
-// internal (tests/test_gpu_refmath.py): acos(x[i]) and atan2(y[i], x[i]) as the device's White kernels evaluate them (tm_refmath.h),
-// host arrays in and out.  Not part of the drop-in surface.
-int tm_debug_white_math(const double* x, const double* y, uint64_t n, double* out_acos, double* out_atan2) {
+// diagnostic (include/tm_hip.h, tests/test_gpu_refmath.py): acos(x[i]) and atan2(y[i], x[i]) as the device's White kernels evaluate
+// them (tm_refmath.h), host arrays in and out
+int tm_white_math_probe(const double* x, const double* y, uint64_t n, double* out_acos, double* out_atan2) {
     return guarded([&]() {
         if (!x || !y || !out_acos || !out_atan2) throw TmError(TM_E_ARG, "null argument");
         require_gfx950();
@@ -232,6 +234,16 @@ int tm_smoother_iterate_until(tm_smoother* s, uint64_t max_iterations, double sc
         if (!(scaled_residual_tol > 0.0)) throw TmError(TM_E_ARG, "the residual tolerance must be positive");
         tm_stats st;
         const bool reached = s->impl.iterate_until(max_iterations, scaled_residual_tol, &st);
+        if (stats) *stats = st;
+        return (reached && !st.not_converged) ? TM_OK : TM_W_NOT_CONVERGED;
+    });
+}
+int tm_smoother_iterate_until_update(tm_smoother* s, uint64_t max_iterations, double update_rms_tol, tm_stats* stats) {
+    return guarded([&]() {
+        if (!s) throw TmError(TM_E_ARG, "null handle");
+        if (!(update_rms_tol > 0.0)) throw TmError(TM_E_ARG, "the update tolerance must be positive");
+        tm_stats st;
+        const bool reached = s->impl.iterate_until_update(max_iterations, update_rms_tol, &st);
         if (stats) *stats = st;
         return (reached && !st.not_converged) ? TM_OK : TM_W_NOT_CONVERGED;
     });

@@ -3,6 +3,7 @@
 #include "../../include/tm_hip.h"
 #include "tm_smoother.hpp"
 
+#include <cmath>
 #include <new>
 #include <string>
 

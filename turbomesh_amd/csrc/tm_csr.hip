@@ -143,9 +143,9 @@ extern "C" int tm_csr_solve(uint64_t n64, const int32_t* Ap, const int32_t* Ai, 
         tm_solver_opt opt;
         std::memset(&opt, 0, sizeof(opt));
         if (opt_in) opt = *opt_in;
-        if (!(opt.rtol > 0)) opt.rtol = 1e-14;
+        if (!(opt.rtol > 0)) opt.rtol = default_rtol(static_cast<double>(n));
         if (!(opt.atol > 0)) opt.atol = 0.0;
-        if (opt.max_inner == 0) opt.max_inner = 10000;   // the reference caps at 1000 (BiCGStab.zig:19) -- with its far looser stop test
+        if (opt.max_inner == 0) opt.max_inner = default_max_inner(static_cast<double>(n));
         if (opt.check_every == 0) opt.check_every = 8;
 
         int dev = 0;

@@ -852,17 +852,26 @@ __global__ __launch_bounds__(256) void k_relax2(Relax2Block a, int RI, int nSG, 
 // Ordering against another queue from inside a kernel (Smoother::relax_pairs_pipelined): every workgroup of a WAITED launch spins
 // on the counter before it touches memory, then acquires at agent scope (the producer's kernels ended with a release); the first
 // thread of a SIGNALLING launch publishes that everything in front of the launch in its queue is complete.
-__device__ __forceinline__ void queue_wait_in_kernel(const QueueWait& w) {
-    if (threadIdx.x == 0) {
-        unsigned polls = 0;
-        while (__hip_atomic_load(w.counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < w.target) {
-            __builtin_amdgcn_s_sleep(16);
-            if (++polls > (1u << 25)) {   // fail the pass rather than hang the device
-                __hip_atomic_store(w.error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                break;
-            }
+// One thread's wait for `*counter >= target`: relaxed polls with sleeps.  The limit is generous (tens of seconds: the first exchange of
+// a new communicator sets up its connections and can take seconds, and everything queued behind it waits that long); a wait that
+// runs into it raises *error and gives up, and so does every later wait of the pass at once (it looks at *error first and every
+// 4096 polls) -- a pass whose ordering failed drains in seconds and returns TM_E_HIP instead of holding the device for
+// (number of waits) x the limit.
+__device__ __forceinline__ void spin_until(const uint32_t* counter, uint32_t target, uint32_t* error) {
+    if (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    unsigned polls = 0;
+    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
+        __builtin_amdgcn_s_sleep(16);
+        ++polls;
+        if ((polls & 4095u) == 0u && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (polls > (1u << 25)) {   // fail the pass rather than hang the device
+            __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            break;
         }
     }
+}
+__device__ __forceinline__ void queue_wait_in_kernel(const QueueWait& w) {
+    if (threadIdx.x == 0) spin_until(w.counter, w.target, w.error);
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
@@ -1732,32 +1741,15 @@ __global__ __launch_bounds__(64) void k_queue_signal(uint32_t* counter) {
     if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
 __global__ __launch_bounds__(64) void k_queue_wait(const uint32_t* counter, uint32_t target, uint32_t* error) {
-    if (threadIdx.x != 0) return;
     // relaxed polls (an acquire per poll would invalidate this XCD's L2 every microsecond under the interior pass); the kernels
-    // behind this one start with the usual start-of-kernel acquire and see what the signalling queue had completed.  The limit is
-    // generous (tens of seconds): the first exchange of a new communicator sets up its connections and can take seconds, and
-    // everything queued behind it waits that long
-    unsigned polls = 0;
-    while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(16);
-        if (++polls > (1u << 25)) {   // fail the pass rather than hang the device
-            __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-    }
+    // behind this one start with the usual start-of-kernel acquire and see what the signalling queue had completed
+    if (threadIdx.x == 0) spin_until(counter, target, error);
 }
 // both in one launch (a kernel boundary less on the handle's stream): announce what precedes, then wait for the other queue
 __global__ __launch_bounds__(64) void k_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error) {
     if (threadIdx.x != 0) return;
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    unsigned polls = 0;
-    while (__hip_atomic_load(other, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
-        __builtin_amdgcn_s_sleep(16);
-        if (++polls > (1u << 25)) {
-            __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            break;
-        }
-    }
+    spin_until(other, target, error);
 }
 hipError_t launch_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error, hipStream_t st) {
     hipLaunchKernelGGL(k_queue_signal_wait, dim3(1), dim3(64), 0, st, counter, other, target, error);
@@ -2450,7 +2442,7 @@ hipError_t launch_white(const WhiteArgs& w, int update, hipStream_t st) {
 }
 
 
-// test hook (tm_debug_white_math): the two libm functions of the White control function, evaluated on the device
+// diagnostic (tm_white_math_probe): the two libm functions of the White control function, evaluated on the device
 __global__ __launch_bounds__(256) void k_debug_white_math(const double* __restrict__ x, const double* __restrict__ y, uint64_t n, double* __restrict__ out_acos,
                                                           double* __restrict__ out_atan2) {
     const uint64_t i = blockIdx.x * 256ull + threadIdx.x;

@@ -18,6 +18,7 @@
 #include <memory>
 #include <mutex>
 #include <string>
+#include <type_traits>
 #include <vector>
 
 namespace tmh {
@@ -97,6 +98,36 @@ struct tm_rccl_comm {
     std::vector<int32_t> owner, peer;
     std::vector<int64_t> send_off, send_cnt, recv_off, recv_cnt;
 };
+
+namespace tmh {
+
+// What one rank hands to ncclSend / ncclRecv per exchange: for every neighbouring rank an offset + count (rows) into the send
+// buffer the handle passes (its own vector when every send list is one run of local rows, else the packed rows) and into the
+// ghost segment.  A pure function of topology + partition, so that the property that matters -- rank a's send to b has exactly the
+// size of b's receive from a, for every pair, or ncclGroupEnd never returns -- is checkable without a communicator
+// (tm_rccl_peer_table_build, tests/test_rccl_peer_tables.py).
+struct PeerTable {
+    std::vector<int32_t> peer;
+    std::vector<int64_t> send_off, send_cnt, recv_off, recv_cnt;
+    int64_t send_rows = 0, recv_rows = 0;   // extent of the two buffers the offsets index
+    bool direct_send = false;
+};
+
+static PeerTable peer_table_of(const LocalPlan& lp) {
+    PeerTable t;
+    t.peer.assign(lp.peer_rank.begin(), lp.peer_rank.end());
+    t.direct_send = lp.direct_send;
+    if (lp.direct_send) t.send_off.assign(lp.send_first.begin(), lp.send_first.end());   // the handle passes the vector itself as send buffer
+    else t.send_off.assign(lp.send_off.begin(), lp.send_off.end());
+    t.send_cnt.assign(lp.send_cnt.begin(), lp.send_cnt.end());
+    t.recv_off.assign(lp.recv_off.begin(), lp.recv_off.end());
+    t.recv_cnt.assign(lp.recv_cnt.begin(), lp.recv_cnt.end());
+    t.send_rows = lp.direct_send ? lp.n_owned + static_cast<int64_t>(lp.ghost_gid.size()) : static_cast<int64_t>(lp.send_ids.size());
+    t.recv_rows = static_cast<int64_t>(lp.ghost_gid.size());
+    return t;
+}
+
+}  // namespace tmh
 
 namespace {
 
@@ -201,6 +232,7 @@ void tm_rccl_comm_destroy(tm_rccl_comm* c) {
     delete c;
 }
 
+#ifdef TM_DEBUG_EXPORTS   // `make DEBUG_EXPORTS=1`: measurement helpers, not part of include/tm_hip.h (tools/README.md)
 // internal (tools/split_path_cost.py): hooks that move nothing, to time the multi-rank schedule of ONE rank without its peers.
 // The ghost rows stay stale, so the coordinates are meaningless.  Not part of the drop-in surface.
 int tm_debug_null_hooks(int32_t rank, int32_t nranks, const int32_t* owner, tm_comm_hooks* hooks) {
@@ -250,6 +282,47 @@ int tm_debug_rccl_selftest(tm_rccl_comm* c, int64_t rows, int32_t iters, double*
         return TM_OK;
     });
 }
+#endif   // TM_DEBUG_EXPORTS
+
+int tm_rccl_peer_table_build(const tm_mesh_desc* mesh, const int32_t* owner, int32_t rank, int32_t nranks, tm_rccl_peer_table* out) {
+    return guarded([&]() {
+        if (!mesh || !owner || !out || nranks < 1 || rank < 0 || rank >= nranks) throw TmError(TM_E_ARG, "bad argument");
+        std::memset(out, 0, sizeof(*out));
+        const Topology topo = topo_of(mesh);
+        std::vector<int32_t> own(owner, owner + topo.nblocks());
+        for (int32_t o : own)
+            if (o < 0 || o >= nranks) throw TmError(TM_E_ARG, "owner rank out of range");
+        const PeerTable t = peer_table_of(build_local_plan(topo, build_rows(topo), own, rank, nranks));
+        const size_t n = t.peer.size();
+        out->npeers = static_cast<int32_t>(n);
+        out->direct_send = t.direct_send ? 1 : 0;
+        out->send_rows = t.send_rows;
+        out->recv_rows = t.recv_rows;
+        auto dup = [&](const auto& v) {
+            using T = typename std::decay_t<decltype(v)>::value_type;
+            T* p = static_cast<T*>(std::malloc(sizeof(T) * (n ? n : 1)));
+            if (!p) throw TmError(TM_E_MEMORY, "malloc failed");
+            if (n) std::memcpy(p, v.data(), sizeof(T) * n);
+            return p;
+        };
+        out->peer = dup(t.peer);
+        out->send_off = dup(t.send_off);
+        out->send_cnt = dup(t.send_cnt);
+        out->recv_off = dup(t.recv_off);
+        out->recv_cnt = dup(t.recv_cnt);
+        return TM_OK;
+    });
+}
+
+void tm_rccl_peer_table_free(tm_rccl_peer_table* t) {
+    if (!t) return;
+    std::free(t->peer);
+    std::free(t->send_off);
+    std::free(t->send_cnt);
+    std::free(t->recv_off);
+    std::free(t->recv_cnt);
+    std::memset(t, 0, sizeof(*t));
+}
 
 int tm_rccl_hooks(tm_rccl_comm* c, const tm_mesh_desc* mesh, const int32_t* owner, tm_comm_hooks* hooks) {
     return guarded([&]() {
@@ -259,12 +332,12 @@ int tm_rccl_hooks(tm_rccl_comm* c, const tm_mesh_desc* mesh, const int32_t* owne
         for (int32_t o : c->owner)
             if (o < 0 || o >= c->nranks) throw TmError(TM_E_ARG, "owner rank out of range");
         const LocalPlan lp = build_local_plan(topo, build_rows(topo), c->owner, c->rank, c->nranks);
-        c->peer.assign(lp.peer_rank.begin(), lp.peer_rank.end());
-        if (lp.direct_send) c->send_off.assign(lp.send_first.begin(), lp.send_first.end());   // the handle passes the vector itself as send buffer
-        else c->send_off.assign(lp.send_off.begin(), lp.send_off.end());
-        c->send_cnt.assign(lp.send_cnt.begin(), lp.send_cnt.end());
-        c->recv_off.assign(lp.recv_off.begin(), lp.recv_off.end());
-        c->recv_cnt.assign(lp.recv_cnt.begin(), lp.recv_cnt.end());
+        PeerTable t = peer_table_of(lp);
+        c->peer = std::move(t.peer);
+        c->send_off = std::move(t.send_off);
+        c->send_cnt = std::move(t.send_cnt);
+        c->recv_off = std::move(t.recv_off);
+        c->recv_cnt = std::move(t.recv_cnt);
         std::memset(hooks, 0, sizeof(*hooks));
         hooks->ctx = c;
         hooks->rank = c->rank;

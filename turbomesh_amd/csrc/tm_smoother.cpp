@@ -148,9 +148,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         throw TmError(TM_E_UNSUPPORTED, "ExternalSolverNotEnabled: libtm_hip serves only solver tag `hip` (gmres/bicgstab/umfpack/petsc stay on the Zig side)");
     if (o->inner != TM_INNER_BICGSTAB && o->inner != TM_INNER_RELAX && o->inner != TM_INNER_MG_BICGSTAB) throw TmError(TM_E_ARG, "unknown inner strategy");
     opt = *o;
-    if (!(opt.rtol > 0)) opt.rtol = 1e-14;
     if (!(opt.atol > 0)) opt.atol = 0.0;
-    if (opt.max_inner == 0) opt.max_inner = 10000;   // the reference caps at 1000 (BiCGStab.zig:19) -- with its far looser stop test
     if (opt.check_every == 0) opt.check_every = (opt.inner == TM_INNER_MG_BICGSTAB) ? 1 : 8;   // a multigrid-preconditioned iteration costs ~100x a poll
     if (!(opt.omega > 0)) opt.omega = 1.0;
     cf = c ? *c : tm_control_fn{TM_CF_LAPLACE, 0, 0.0, 0.0};
@@ -159,6 +157,8 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
 
     topo = topology_from_desc(mesh);
     dof_global = topo.dof;
+    if (!(opt.rtol > 0)) opt.rtol = default_rtol(static_cast<double>(dof_global));
+    if (opt.max_inner == 0) opt.max_inner = default_max_inner(static_cast<double>(dof_global));
     try {
         all_rows = build_rows(topo);
         has_hooks = h != nullptr && h->nranks >= 1 && h->exchange != nullptr && h->allreduce_sum != nullptr;
@@ -228,6 +228,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     }
     // two sweeps per pass (K2x2): Laplace control function only (White updates P,Q between sweeps), every owned block >= 5 x 5
     fuse_pairs = opt.inner == TM_INNER_RELAX && !white && !(opt.flags & TM_OPT_SINGLE_SWEEP);
+    { const char* e = std::getenv("TM_PAIR_SYNC"); pair_sync_events = e && std::strcmp(e, "events") == 0; }
     // (every block of the mesh, not just the owned ones: the ranks of a job must agree on the schedule -- a pair costs one exchange)
     for (int64_t b = 0; b < topo.nblocks(); ++b)
         if (has_hooks || owner[b] == lp.rank) fuse_pairs = fuse_pairs && relax2_supported(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
@@ -1071,8 +1072,7 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
     // deadlock even if both streams share a hardware queue; a wait that is not met within tens of seconds raises sync_flags[2] and
     // the pass fails with TM_E_HIP instead of hanging the device.  Several multi-rank handles in ONE process (the virtual-rank tests) could
     // block each other through shared hardware queues: they use events.
-    static const bool events_env = [] { const char* e = std::getenv("TM_PAIR_SYNC"); return e && std::strcmp(e, "events") == 0; }();
-    const bool use_flags = !events_env && g_multirank_handles.load() <= 1;
+    const bool use_flags = !pair_sync_events && g_multirank_handles.load() <= 1;
     uint32_t* border_done = sync_flags;
     uint32_t* inside_done = sync_flags + 1;
     uint32_t* sync_err = sync_flags + 2;
@@ -1231,6 +1231,38 @@ void Smoother::iterate(uint64_t iterations, tm_stats* stats) {
     sync();
     st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     if (stats) *stats = st;
+}
+
+// Outer iterations until the UPDATE of the last one, sqrt((sum dx^2 + sum dy^2) / dof) over all nodes of the mesh, is <= tol: the
+// quantity the reference itself forms and logs every iteration (smooth.zig:112-137, it prints its square squared) -- a distance
+// between consecutive iterates, i.e. a statement about convergence of the coordinates, which the scaled residual (~ h^2 x the
+// displacement a point-Jacobi step would make) is not on a fine mesh.  Relax mode tests every 32 sweeps.
+bool Smoother::iterate_until_update(uint64_t max_iterations, double tol, tm_stats* stats) {
+    const auto t0 = std::chrono::steady_clock::now();
+    tm_stats st;
+    std::memset(&st, 0, sizeof(st));
+    bool reached = false;
+    const tm_log_fn sink = g_log_sink;
+    while (st.outer_iterations < max_iterations) {
+        if (opt.inner == TM_INNER_RELAX) {
+            const uint64_t n = std::min<uint64_t>(32, max_iterations - st.outer_iterations);
+            relax_sweeps(n, st);
+            st.outer_iterations += n;
+        } else {
+            if (sink) sink(g_log_ctx, 0, st.outer_iterations, 0.0);
+            st.not_converged += picard_bicgstab(st);
+            if (sink) sink(g_log_ctx, 1, st.outer_iterations, st.last_residual);
+            st.outer_iterations += 1;
+        }
+        if (std::sqrt((st.last_dx2 + st.last_dy2) / static_cast<double>(dof_global)) <= tol) {
+            reached = true;
+            break;
+        }
+    }
+    sync();
+    st.seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (stats) *stats = st;
+    return reached;
 }
 
 // Outer iterations until the scaled nonlinear residual sqrt(||D^-1 (b - A(X) X)||^2 / (2 dof)) is <= tol (the reference has no

@@ -4,6 +4,7 @@
 #include "tm_kernels.h"
 #include "tm_multigrid.hpp"
 #include "tm_plan.hpp"
+#include <cmath>
 #include <atomic>
 #include <memory>
 #include <string>
@@ -69,6 +70,7 @@ struct Smoother {
     void precondition(const double2* in, double2* out);
     double2* M = nullptr;           // X^(k+1) of a fused pair of relax sweeps (perimeter + first-interior ring only)
     bool fuse_pairs = false;
+    bool pair_sync_events = false;   // TM_PAIR_SYNC=events when the handle was created: multi-rank sweep pairs ordered by events, not device counters
     size_t inside_lds = 0;          // dynamic LDS of the interior pass of a multi-rank sweep pair (occupancy cap, see create())
     // perimeter rows
     EdgeRowsDev edge;
@@ -127,7 +129,8 @@ struct Smoother {
     void upload(const tm_mesh_desc* mesh);
     void download(const tm_mesh_desc* mesh);
     void iterate(uint64_t iterations, tm_stats* stats);
-    bool iterate_until(uint64_t max_iterations, double tol, tm_stats* stats);   // true = the scaled residual reached tol
+    bool iterate_until(uint64_t max_iterations, double tol, tm_stats* stats);
+    bool iterate_until_update(uint64_t max_iterations, double tol, tm_stats* stats);   // true = the scaled residual reached tol
     double stop_tol = 0.0;          // > 0: a Picard iteration whose start residual is already <= stop_tol returns without solving
     void apply_host(const double* in_xy, double* out_xy, int scaled);
     void rhs_host(double* rhs_xy);
@@ -180,6 +183,23 @@ struct Smoother {
     void profiled(const std::function<void()>& launch, bool counts = true, hipStream_t on = nullptr);
     void relax2_launch(int subset, bool counts, int dot, hipStream_t on = nullptr, const QueueWait* wait = nullptr);
 };
+
+// Defaults of the inner solve that depend on the size of the system (tm_solver_opt.rtol == 0, max_inner == 0).
+// The stop test bounds the scaled RESIDUAL; the distance of the Picard iterate from the exact-solve iterate -- what north_star's
+// 1e-10 RMS is about -- is conditioning x residual, and cond(D^-1 A) of the frozen Winslow system grows like the node count.
+// Measured with the diagonal-only BiCGStab against the sparse-LU oracle on perturbed n^2 blocks (tests/test_gpu_parity_ladder.py,
+// tools/dev/picard_ladder.py): rms error ~ 4e-17 .. 1e-16 x nodes x (rtol / 1e-14) -- 2e-11 at 1025^2,
+// 6.5e-11 at 2049^2 and 6e-10 at 4096^2 with rtol 1e-14.  Hence rtol = 7.5e-9 / nodes, between 1e-16 and 1e-14: every size lands
+// at <= 3e-11, for 0-40 % more inner iterations on the large meshes (the recurrence residual keeps falling; no stagnation seen down
+// to 1e-16).  The iteration cap grows with the mesh too: BiCGStab with the diagonal alone needs ~3-5 sqrt(nodes) iterations.
+inline double default_rtol(double nodes) {
+    const double r = 7.5e-9 / (nodes > 1.0 ? nodes : 1.0);
+    return r > 1e-14 ? 1e-14 : (r < 1e-16 ? 1e-16 : r);
+}
+inline uint64_t default_max_inner(double nodes) {
+    const double k = 12.0 * std::sqrt(nodes > 1.0 ? nodes : 1.0);
+    return k > 10000.0 ? static_cast<uint64_t>(k) : 10000u;   // the reference caps at 1000 (BiCGStab.zig:19) -- with its far looser stop test
+}
 
 }  // namespace tmh
 

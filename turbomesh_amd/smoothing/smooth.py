@@ -111,6 +111,15 @@ class Smoother:
             _capi.check(rc)
         return rc == 0, st.as_dict()
 
+    def iterate_until_update(self, update_rms_tol: float, max_iterations: int = 1000):
+        """Iterate until the last outer iteration moved the nodes by <= tol RMS (the reference's per-iteration quantity,
+        smooth.zig:112-137).  Returns (reached, stats)."""
+        st = _capi.tm_stats()
+        rc = _capi.lib().tm_smoother_iterate_until_update(self._h, max_iterations, C.c_double(update_rms_tol), C.byref(st))
+        if rc < 0:
+            _capi.check(rc)
+        return rc == 0, st.as_dict()
+
     def download(self):
         _capi.check(_capi.lib().tm_smoother_download(self._h, self._md.ref()))
 

@@ -42,9 +42,9 @@ class Option:
     tag: Tag = Tag.hip
     preconditioner: Preconditioner = Preconditioner.diagonal   # payload of gmres / bicgstab
     inner: Inner = Inner.bicgstab
-    rtol: float = 0.0          # 0 -> library default 1e-14 (scaled residual)
+    rtol: float = 0.0          # 0 -> library default: 7.5e-9 / nodes within [1e-16, 1e-14] (scaled residual)
     atol: float = 0.0
-    max_inner: int = 0         # 0 -> 10000 (the reference: 1000, BiCGStab.zig:19, with its looser stop test)
+    max_inner: int = 0         # 0 -> max(10000, 12 sqrt(nodes)) (the reference: 1000, BiCGStab.zig:19, with its looser stop test)
     check_every: int = 0       # 0 -> 8
     omega: float = 0.0         # 0 -> 1.0
     single_sweep: bool = False # relax: one kernel pass per sweep (default: two sweeps per pass where possible)
