@@ -479,6 +479,16 @@ def main():
                                    + (f", {tj.get('date')}" if tj.get("date") else "") + ("; STALE (kernel source changed since), dropped" if stale else ""))
             except Exception:
                 traffic = None
+        # the measured ceiling beside the specification: copy / triad at this workload's footprint, in this run
+        import ctypes as C
+
+        cp, tr = C.c_double(0), C.c_double(0)
+        try:
+            _capi.check(_capi.lib().tm_stream_probe(int(16 * nodes_rank), 20, C.byref(cp), C.byref(tr)))
+            stream = {"copy": cp.value, "triad": tr.value}
+        except Exception as e:   # noqa: BLE001 -- a diagnostic must not cost the line
+            print(f"[bench] stream probe failed: {e}", file=sys.stderr)
+            stream = None
         out = {
             "metric": f"nodes smoothed/sec (elliptic sweeps, {n}^2 blocks) + achieved HBM GB/s",
             "value": value, "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -491,6 +501,10 @@ def main():
                        "sweep_equiv_GBps_whole_job": BYTES_PER_NODE * value / 1e9},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "stream_ceiling_GBps": (max(stream.values()) if stream else None),
+                         "frac_of_stream": (achieved / max(stream.values()) if stream else None),
+                         "stream": ({**stream, "what": f"tm_stream_probe in this run: copy / triad of {16 * nodes_rank / 2**20:.0f} MiB per array, non-temporal 16 B/lane, 20 launches each"}
+                                    if stream else None),
                          "kernel": "k_relax2<DELTA> (K2x2: two winslow sweeps per launch)" if fused else "k_apply<RELAX,DELTA,field,laplace> (K2 winslow_apply)",
                          "sweeps_per_launch": sweeps_per_launch, "bytes_per_launch": bytes_per_launch,
                          "bytes_model": "32 B per owned node per LAUNCH: the field is read once and written once per pass (rank 0's blocks)",

@@ -357,6 +357,11 @@ typedef struct tm_plan_local_info {
 int tm_plan_local(const tm_mesh_desc* mesh, const int32_t* owner, int32_t rank, int32_t nranks, tm_plan_local_info* out);
 void tm_plan_local_free(tm_plan_local_info* info);
 
+/* Diagnostic: the STREAM-style ceiling of this GPU at a footprint of `bytes` per array (SURVEY 8d asks for it beside the 8 TB/s
+ * specification): copy (b = a: 2 x bytes moved) and triad (a = b + s c: 3 x bytes), 16 B per lane, non-temporal loads and stores --
+ * the access pattern of the library's vector kernels -- averaged over `iters` launches after 3 warm-up launches; GB/s = 1e9 B/s. */
+int tm_stream_probe(uint64_t bytes, int32_t iters, double* copy_GBps, double* triad_GBps);
+
 /* Diagnostic: acos(x[i]) and atan2(y[i], x[i]) exactly as the White kernels evaluate them on the device (csrc/tm_refmath.h: the
  * reference's libm algorithm, Zig std.math = musl's, wall_control_function.zig:298-308).  Host arrays in and out. */
 int tm_white_math_probe(const double* x, const double* y, uint64_t n, double* out_acos, double* out_atan2);

@@ -116,7 +116,7 @@ EXPORTS = [
     "tm_smoother_exchange_plan", "tm_smoother_apply", "tm_smoother_rhs", "tm_smoother_row_kinds", "tm_smoother_dof",
     "tm_smoother_control_function", "tm_smoother_profile", "tm_smoother_profile_read", "tm_plan_build", "tm_plan_free", "tm_plan_local", "tm_plan_local_free", "tm_dev_tfi_block", "tm_dev_relax_sweep",
     "tm_dev_relax_partials_needed", "tm_export_soa", "tm_smoother_export_soa", "tm_rccl_unique_id", "tm_rccl_comm_create", "tm_rccl_comm_destroy", "tm_rccl_hooks",
-    "tm_rccl_peer_table_build", "tm_rccl_peer_table_free", "tm_white_math_probe",
+    "tm_rccl_peer_table_build", "tm_rccl_peer_table_free", "tm_white_math_probe", "tm_stream_probe",
 ]
 
 _lib = None
@@ -205,6 +205,7 @@ def lib():
         L.tm_rccl_peer_table_free.argtypes = [C.POINTER(tm_rccl_peer_table)]
         L.tm_rccl_peer_table_free.restype = None
         L.tm_white_math_probe.argtypes = [_dp, _dp, C.c_uint64, _dp, _dp]
+        L.tm_stream_probe.argtypes = [C.c_uint64, C.c_int32, _dp, _dp]
         if hasattr(L, "tm_tune_apply"):   # measurement build (TM_HIP_LIB=.../libtm_hip_dbg.so, tools/)
             L.tm_debug_null_hooks.argtypes = [C.c_int32, C.c_int32, C.POINTER(C.c_int32), C.POINTER(tm_comm_hooks)]
             L.tm_diag_apply.argtypes = [C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint64, C.c_int, C.c_void_p]

@@ -85,6 +85,38 @@ int tm_diag_apply(const double* d_in, double* d_out, uint64_t ni, uint64_t nj, i
 #endif   // TM_DEBUG_EXPORTS
 
 // ------------------------------------------------------------------ TFI (tfi.zig:112-208)
+// diagnostic (include/tm_hip.h): what this GPU sustains on a plain copy / triad of `bytes` per array, vector-kernel access pattern
+int tm_stream_probe(uint64_t bytes, int32_t iters, double* copy_GBps, double* triad_GBps) {
+    return guarded([&]() {
+        if (bytes < 4096 || iters < 1 || !copy_GBps || !triad_GBps) throw TmError(TM_E_ARG, "bad argument");
+        require_gfx950();
+        const int64_t n = static_cast<int64_t>(bytes / sizeof(double2));
+        DevBuf a(sizeof(double2) * n), b(sizeof(double2) * n), c(sizeof(double2) * n);
+        HIPCHK(hipMemset(a.p, 0, sizeof(double2) * n));
+        HIPCHK(hipMemset(b.p, 0, sizeof(double2) * n));
+        HIPCHK(hipMemset(c.p, 0, sizeof(double2) * n));
+        hipEvent_t e0, e1;
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+        double out[2] = {0.0, 0.0};
+        for (int kind = 0; kind < 2; ++kind) {
+            for (int w = 0; w < 3; ++w) HIPCHK(launch_stream(kind, a.as<double2>(), b.as<double2>(), c.as<double2>(), 0.5, n, nullptr));
+            HIPCHK(hipEventRecord(e0, nullptr));
+            for (int k = 0; k < iters; ++k) HIPCHK(launch_stream(kind, a.as<double2>(), b.as<double2>(), c.as<double2>(), 0.5, n, nullptr));
+            HIPCHK(hipEventRecord(e1, nullptr));
+            HIPCHK(hipEventSynchronize(e1));
+            float ms = 0.f;
+            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            out[kind] = static_cast<double>(kind == 1 ? 3 : 2) * sizeof(double2) * n * iters / (1e-3 * ms) / 1e9;
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        *copy_GBps = out[0];
+        *triad_GBps = out[1];
+        return TM_OK;
+    });
+}
+
 // diagnostic (include/tm_hip.h, tests/test_gpu_refmath.py): acos(x[i]) and atan2(y[i], x[i]) as the device's White kernels evaluate
 // them (tm_refmath.h), host arrays in and out
 int tm_white_math_probe(const double* x, const double* y, uint64_t n, double* out_acos, double* out_atan2) {

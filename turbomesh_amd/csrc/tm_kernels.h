@@ -252,6 +252,7 @@ hipError_t launch_xr_update_vs(const LazyScalars& S, double2* u, const double2* 
 // K7: partials sum (xk-u)^2 (x,y); xk <- u
 hipError_t launch_residual_copyback(double2* xk, const double2* u, int64_t n, double* partials, hipStream_t stream);
 // gather rows for the halo exchange: dst[k] = src[ids[k]]
+hipError_t launch_stream(int kind, double2* a, const double2* b, const double2* c, double s, int64_t n, hipStream_t stream);
 hipError_t launch_gather_rows(const double2* src, const int32_t* ids, int64_t n, double2* dst, hipStream_t stream);
 
 // out perimeter <- in perimeter of one block (fixed boundary of the stand-alone relax sweep)

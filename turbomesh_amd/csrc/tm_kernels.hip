@@ -2177,6 +2177,35 @@ hipError_t launch_residual_copyback(double2* xk, const double2* u, int64_t n, do
     return hipGetLastError();
 }
 
+// STREAM-style ceiling of this part at a given footprint, with the access pattern the vector kernels use (16 B per lane,
+// non-temporal loads and stores, all loads of a trip issued before the first store): kind 0 = copy (b = a), 1 = triad
+// (a = b + s c).  What `roofline.stream_ceiling_GBps` of bench.py reports beside the 8 TB/s specification.
+template <int KIND>
+__global__ __launch_bounds__(VEC_BLOCK) void k_stream(double2* __restrict__ a, const double2* __restrict__ b, const double2* __restrict__ c, double s,
+                                                      int64_t n) {
+    constexpr int UN = 4;
+    const int64_t stride = static_cast<int64_t>(gridDim.x) * VEC_BLOCK;
+    for (int64_t i0 = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i0 < n; i0 += stride * UN) {
+        double2 x[UN], y[UN];
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int64_t i = min(i0 + q * stride, n - 1);
+            x[q] = load_nt(b + i);
+            if (KIND == 1) y[q] = load_nt(c + i);
+        }
+#pragma unroll
+        for (int q = 0; q < UN; ++q) {
+            const int64_t i = i0 + q * stride;
+            if (i < n) store_nt(a + i, KIND == 1 ? make_double2(x[q].x + s * y[q].x, x[q].y + s * y[q].y) : x[q]);
+        }
+    }
+}
+hipError_t launch_stream(int kind, double2* a, const double2* b, const double2* c, double s, int64_t n, hipStream_t st) {
+    if (kind == 1) hipLaunchKernelGGL(k_stream<1>, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, a, b, c, s, n);
+    else hipLaunchKernelGGL(k_stream<0>, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, a, b, c, s, n);
+    return hipGetLastError();
+}
+
 __global__ __launch_bounds__(VEC_BLOCK) void k_gather_rows(const double2* __restrict__ src, const int32_t* __restrict__ ids, int64_t n,
                                                            double2* __restrict__ dst) {
     for (int64_t i = blockIdx.x * static_cast<int64_t>(VEC_BLOCK) + threadIdx.x; i < n; i += static_cast<int64_t>(gridDim.x) * VEC_BLOCK)
