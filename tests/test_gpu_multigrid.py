@@ -120,6 +120,7 @@ def test_prolongation_folded_into_the_post_smoothing_sweep_is_bit_identical(shap
     # the correction interpolated as the rows enter K2's window (even / odd rows and columns, wave seams at columns 64 k, semi-coarsened
     # levels of stretched blocks, halo columns) against the stand-alone k_mg_prolong_add: same expression, same bits
     out = []
+    monkeypatch.setenv("TM_MG_PAIR", "0")   # the one-sweep-per-pass cycle (the two-per-pass kernels have their own test below)
     for fused in ("2", "0"):   # 2 = the folded form on every level, 0 = never
         monkeypatch.setenv("TM_MG_FUSE_PROLONG", fused)
         mesh = configs.single_block(shape[0], shape[1], perturb=0.25)
@@ -136,8 +137,47 @@ def test_folded_prolongation_with_a_control_function_and_many_blocks(monkeypatch
     # the (P, Q) flavour of the folded kernel and multi-block meshes: the White plate and T106 (8 blocks, semi-coarsened levels)
     for build, control in ((TOPOLOGIES["plate_le"], wcf.Algorithm(wcf.White(0.02))), (lambda: load("T106", None)[1], None)):
         out = []
+        monkeypatch.setenv("TM_MG_PAIR", "0")
         for fused in ("2", "0"):
             monkeypatch.setenv("TM_MG_FUSE_PROLONG", fused)
+            mesh = build()
+            with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-12, max_inner=400, check_every=1), control) as sm:
+                st = sm.iterate(2)
+                sm.download()
+            assert st["not_converged"] == 0
+            out.append((mesh_flat(mesh), st["inner_iterations"]))
+        assert out[0][1] == out[1][1]
+        assert np.array_equal(out[0][0], out[1][0])
+
+
+PAIR_SHAPES = [(129, 257), (100, 131), (67, 300), (33, 33), (5, 70), (300, 9), (61, 62), (64, 121), (6, 5), (250, 241), (1000, 700), (2049, 1030)]
+
+
+@pytest.mark.parametrize("shape", PAIR_SHAPES, ids=[f"{a}x{b}" for a, b in PAIR_SHAPES])
+def test_two_operator_applications_per_pass_are_bit_identical(shape, monkeypatch):
+    # k_mg_pair -- both pre-sweeps + the residual in one pass, the prolongation + both post-sweeps in one pass, on every level of at
+    # least 5 x 5 nodes -- against the one-sweep-per-pass kernels (TM_MG_PAIR=0): the same operation sequence per node, so the
+    # same bits after whole Picard solves.  Shapes: strip seams at columns 60 k, chunk seams, even / odd sizes (short last
+    # coarse cell), a direction too short to coarsen, semi-coarsened levels, levels that fall back to the old kernels (3 x n).
+    out = []
+    for pair in ("1", "0"):
+        monkeypatch.setenv("TM_MG_PAIR", pair)
+        mesh = configs.single_block(shape[0], shape[1], perturb=0.25)
+        with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-12, max_inner=200, check_every=1)) as sm:
+            st = sm.iterate(2)
+            sm.download()
+        assert st["not_converged"] == 0
+        out.append((mesh.blocks[0].points.data.copy(), st["inner_iterations"]))
+    assert out[0][1] == out[1][1]
+    assert np.array_equal(out[0][0], out[1][0]), float(np.abs(out[0][0] - out[1][0]).max())
+
+
+def test_two_per_pass_with_a_control_function_and_many_blocks(monkeypatch):
+    # the (P, Q) flavours (White plate) and multi-block meshes with stretched cells (T106: 8 blocks, semi-coarsened levels)
+    for build, control in ((TOPOLOGIES["plate_le"], wcf.Algorithm(wcf.White(0.02))), (lambda: load("T106", None)[1], None)):
+        out = []
+        for pair in ("1", "0"):
+            monkeypatch.setenv("TM_MG_PAIR", pair)
             mesh = build()
             with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-12, max_inner=400, check_every=1), control) as sm:
                 st = sm.iterate(2)

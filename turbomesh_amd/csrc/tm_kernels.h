@@ -294,6 +294,24 @@ hipError_t launch_mg_restrict(const double2* r_fine, const double2* X_coarse, do
 // e' = e_fine + bilinear interpolation of e_coarse formed as the rows enter K2's window (k_mg_prolong_add's expression: the same
 // bits), e' itself never stored.  a.in = e_fine, a.in2 = e_coarse, a.aux = f, a.xk / a.pq = the level's frozen field.
 hipError_t launch_mg_prolong_smooth(const ApplyBlock& a, const MgPair& g, hipStream_t stream);
+// TWO chained operator applications of a level in one pass (k_mg_pair): kind 0 = two damped-Jacobi sweeps of D^-1 A e = f
+// (in = e with zero perimeter, out = the result; coarse != nullptr: e = e + interpolation of the coarse correction first);
+// kind 1 = the first two sweeps from e = 0 and the residual behind them (in = f, out = e2, out2 = a_ii (f - D^-1 A e2)).
+// Interior nodes only are written.  Bit-identical to the K2 launches it replaces.
+struct MgPairArgs {
+    const double2* in = nullptr;
+    const double2* xk = nullptr;
+    const double2* pq = nullptr;
+    const double2* f = nullptr;       // kind 0: the right-hand side (kind 1: `in` is the right-hand side)
+    double2* out = nullptr;
+    double2* out2 = nullptr;          // kind 1
+    const double2* coarse = nullptr;  // kind 0 with the prolongation folded in
+    int nic = 0, njc = 0, ci = 0, cj = 0;
+    int ni = 0, nj = 0;
+    double omega = 1.0;
+};
+bool mg_pair_supported(int ni, int nj);
+hipError_t launch_mg_pair(const MgPairArgs& a, int kind, hipStream_t stream);
 // e_fine += bilinear interpolation of e_coarse, interior fine nodes
 hipError_t launch_mg_prolong_add(const double2* e_coarse, double2* e_fine, const MgPair& g, hipStream_t stream);
 // out = omega * f on interior nodes, 0 on the perimeter: the first damped-Jacobi sweep from a zero guess

@@ -903,6 +903,224 @@ __global__ __launch_bounds__(256) void k_relax2_batch(Relax2Batch B, int subset)
     relax2_tile<DOT, U, NT, W1>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], subset, static_cast<int>(blockIdx.x) - B.start[k]);
 }
 
+// ------------------------------------------------------------------------------------------
+// Multigrid: TWO chained applications of a level's frozen-coefficient operator in ONE pass over the level -- the K2x2
+// structure (60-of-64 column strips, a 3-row window per stage in registers, rows requested one group ahead, lane / row
+// predicates folded into selects and out-of-range buffer-store offsets) applied to the error equation D^-1 A e = f:
+//   KIND 0 (POST)  s1 = e + omega (f - D^-1 A e);  out = s1 + omega (f - D^-1 A s1)       two damped-Jacobi sweeps
+//                  (PRO: e = e_fine + bilinear interpolation of the coarse correction, formed as the rows enter the window
+//                  with k_mg_prolong_add's expression -- the prolonged iterate is never stored)
+//   KIND 1 (PRE)   e2 = omega (2 f - omega D^-1 A f)  (the first two sweeps from e = 0, MODE_MG_FIRST2's expression);
+//                  out = e2,  out2 = a_ii (f - D^-1 A e2)  (the unscaled residual the restriction averages, MODE_MG_RESID's)
+// Each stage is the operation sequence of winslow_row<MODE_SCALED> on the level's frozen field, so the results are bit-identical to
+// the two K2 launches they replace (tests/test_gpu_multigrid.py); the metric terms of a node (G11, G22, G12, the reciprocal
+// diagonal) are formed ONCE and serve both stages -- the coefficients are frozen -- and the level is read once instead of twice:
+// POST 64 B/node instead of 128 (68 instead of 132 with the prolongation), PRE 64 instead of 112.
+// The error is zero on the block perimeter (tm_multigrid.hpp): the intermediate stage is forced to zero there.
+// ------------------------------------------------------------------------------------------
+struct MgMetric {
+    double G11, G22, mhG12, m2D, D, rinv;
+};
+__device__ __forceinline__ MgMetric mg_metric(double2 dxi, double2 det) {
+    MgMetric m;
+    m.G11 = fma(dxi.x, dxi.x, dxi.y * dxi.y);
+    m.G22 = fma(det.x, det.x, det.y * det.y);
+    const double G12 = fma(dxi.x, det.x, dxi.y * det.y);
+    m.D = m.G11 + m.G22;
+    m.m2D = -2.0 * m.D;
+    m.mhG12 = -0.5 * G12;
+    m.rinv = recip_diag(m.D, m.m2D);
+    return m;
+}
+template <bool HAS_PQ>
+__device__ __forceinline__ double2 mg_scaled_row(const MgMetric& g, const Row3& m, const Row3& c, const Row3& p, double P, double Q) {
+    double ax = p.c.x + m.c.x, ay = p.c.y + m.c.y;
+    double bx = c.h.x, by = c.h.y;
+    if (HAS_PQ) {
+        const double hP = 0.5 * P, hQ = 0.5 * Q;
+        ax = fma(hP, p.c.x - m.c.x, ax);
+        ay = fma(hP, p.c.y - m.c.y, ay);
+        bx = fma(hQ, c.e.x, bx);
+        by = fma(hQ, c.e.y, by);
+    }
+    const double kx = p.e.x - m.e.x;
+    const double ky = p.e.y - m.e.y;
+    double sx = g.G22 * ax, sy = g.G22 * ay;
+    sx = fma(g.G11, bx, sx);
+    sy = fma(g.G11, by, sy);
+    sx = fma(g.m2D, c.c.x, sx);
+    sy = fma(g.m2D, c.c.y, sy);
+    sx = fma(g.mhG12, kx, sx);
+    sy = fma(g.mhG12, ky, sy);
+    return make_double2(sx * g.rinv, sy * g.rinv);
+}
+
+template <int KIND, bool HAS_PQ, bool PRO, int U>
+__device__ __forceinline__ void mg_pair_strip(const MgPairArgs& a, const Relax2Tile& t) {
+    const int ni = a.ni, nj = a.nj;
+    const int cc = min(max(t.c, 0), nj - 1);
+    const double2 zero = make_double2(0.0, 0.0);
+    auto at = [&](int row) { return static_cast<size_t>(min(max(row, 0), ni - 1)) * nj + cc; };
+    const bool perim_col = (t.c <= 0) || (t.c >= nj - 1);
+    const bool col_in = (t.c >= 1) && (t.c <= nj - 2);
+    const int nrows = t.i1 - t.i0;
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + static_cast<size_t>(t.i0) * nj, 0, nrows * nj * 16, 0x00020000);
+    const __amdgpu_buffer_rsrc_t out2_rsrc =
+        __builtin_amdgcn_make_buffer_rsrc((KIND == 1 ? a.out2 : a.out) + static_cast<size_t>(t.i0) * nj, 0, nrows * nj * 16, 0x00020000);
+    const unsigned lane_off = static_cast<unsigned>(cc) * 16u;
+    // PRO: the lane loads the coarse column cj1 of its fine column -- its own when the fine column coincides with a coarse one (even,
+    // or an uncoarsened direction), the one to its right when it lies midway (odd); the column cj0 to the left of a midway column is
+    // then what the PREVIOUS lane loaded (its column is even: lanes and columns have the same parity, the strip starts at 60 s - 2)
+    const int cj1 = PRO ? min(a.cj ? ((cc + 1) >> 1) : cc, a.njc - 1) : 0;
+    const bool midway = PRO && a.cj && (cc & 1);
+
+    struct Ld {   // what one step consumes: row i+2 of `in` and of the frozen field, rhs / control function of row i+1
+        double2 in, x, f, pq, c0, c1;   // c0, c1: the coarse correction at (ci0, cj1), (ci1, cj1)
+    };
+    auto load_step = [&](int i, Ld& L) {
+        const size_t ar = at(i + 2), aq = at(i + 1);
+        L.in = a.in[ar];
+        L.x = a.xk[ar];
+        if (KIND == 0) L.f = a.f[aq];
+        if (HAS_PQ) L.pq = a.pq[aq];
+        if (PRO) {
+            const int r = min(max(i + 2, 0), ni - 1);
+            const int ci0 = min(a.ci ? (r >> 1) : r, a.nic - 1), ci1 = min(a.ci ? ((r + 1) >> 1) : r, a.nic - 1);
+            const double2* r0 = a.coarse + static_cast<size_t>(ci0) * a.njc;
+            const double2* r1 = a.coarse + static_cast<size_t>(ci1) * a.njc;
+            L.c0 = r0[cj1];
+            L.c1 = r1[cj1];
+        }
+    };
+    auto entering = [&](int row, const Ld& L) {   // the value of `in` at (row, this lane's column) as stage 1 sees it
+        if (!PRO) return L.in;
+        // k_mg_prolong_add's expression 0.25 ((a + b) + (c + d)), a = (ci0, cj0), b = (ci0, cj1), c = (ci1, cj0), d = (ci1, cj1);
+        // coinciding indices just repeat a value.  Shifts with every lane active, then the selects.
+        const double2 l0 = lane_prev0(L.c0), l1 = lane_prev0(L.c1);
+        const double2 a0 = midway ? l0 : L.c0, a1 = midway ? l1 : L.c1;
+        const double2 v = make_double2(L.in.x + 0.25 * ((a0.x + L.c0.x) + (a1.x + L.c1.x)), L.in.y + 0.25 * ((a0.y + L.c0.y) + (a1.y + L.c1.y)));
+        return (col_in && row >= 1 && row <= ni - 2) ? v : L.in;
+    };
+    auto det_of = [&](double2 x) { return sub2(lane_next0(x), lane_prev0(x)); };
+
+    Row3 A[3], S[3];
+    double2 Xc[3], Xe_cur;
+    MgMetric Mp = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+    double2 f_prev = zero, pq_prev = zero;
+    Ld cur[U], nxt[U];
+    {   // warm-up: rows i0-2, i0-1 of `in` and of the frozen field
+        Ld w0, w1;
+        load_step(t.i0 - 4, w0);
+        load_step(t.i0 - 3, w1);
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_step(t.i0 - 2 + u, cur[u]);
+        A[0] = make_row(entering(t.i0 - 2, w0));
+        A[1] = make_row(entering(t.i0 - 1, w1));
+        Xc[0] = w0.x;
+        Xc[1] = w1.x;
+        Xe_cur = det_of(w1.x);
+        A[2].c = A[2].e = A[2].h = zero;
+        S[0] = S[1] = S[2] = A[2];
+        Xc[2] = zero;
+    }
+    const int nsteps = nrows + 2;
+    auto group = [&](const int tb) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) load_step(t.i0 - 2 + tb + U + u, nxt[u]);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int A0 = u % 3, A1 = (u + 1) % 3, A2 = (u + 2) % 3;
+            const Ld& L = cur[u];
+            const int i = t.i0 - 2 + tb + u;
+            const int q = i + 1;
+            A[A2] = make_row(entering(i + 2, L));
+            Xc[A2] = L.x;
+            const double2 Xe_next = det_of(L.x);
+            // ---- stage 1 at row q
+            const MgMetric M = mg_metric(sub2(Xc[A2], Xc[A0]), Xe_cur);
+            const double2 t1 = mg_scaled_row<HAS_PQ>(M, A[A0], A[A1], A[A2], HAS_PQ ? L.pq.x : 0.0, HAS_PQ ? L.pq.y : 0.0);
+            const double2 fq = (KIND == 0) ? L.f : A[A1].c;
+            double2 s1;
+            if (KIND == 0) {
+                const double2 res = sub2(fq, t1);
+                s1 = make_double2(fma(a.omega, res.x, A[A1].c.x), fma(a.omega, res.y, A[A1].c.y));
+            } else {
+                s1 = make_double2(a.omega * fma(-a.omega, t1.x, 2.0 * A[A1].c.x), a.omega * fma(-a.omega, t1.y, 2.0 * A[A1].c.y));
+            }
+            const bool perim_row = (q <= 0) || (q >= ni - 1);
+            if (perim_row || perim_col) s1 = zero;   // e = 0 on the block perimeter
+            if (KIND == 1) {   // the chunk that owns row q stores e2
+                const bool own = t.out_lane && !perim_row && (q >= t.i0) && (q < t.i1);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, s1), out_rsrc,
+                                                       static_cast<int>(own ? lane_off + static_cast<unsigned>((q - t.i0) * nj * 16) : OOB_VOFFSET), 0, 0);
+            }
+            S[A2] = make_row(s1);
+            // ---- stage 2 at row i, with the metric formed one step ago
+            const double2 t2 = mg_scaled_row<HAS_PQ>(Mp, S[A0], S[A1], S[A2], HAS_PQ ? pq_prev.x : 0.0, HAS_PQ ? pq_prev.y : 0.0);
+            const double2 res2 = sub2(f_prev, t2);
+            double2 o;
+            if (KIND == 0) {
+                o = make_double2(fma(a.omega, res2.x, S[A1].c.x), fma(a.omega, res2.y, S[A1].c.y));
+            } else {
+                const double aii = -0.5 * Mp.D;
+                o = make_double2(aii * res2.x, aii * res2.y);
+            }
+            const bool live = t.out_lane && (i >= t.i0) && (i < t.i1);
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, o), out2_rsrc,
+                                                   static_cast<int>(live ? lane_off + static_cast<unsigned>((i - t.i0) * nj * 16) : OOB_VOFFSET), 0, 2);
+            Mp = M;
+            f_prev = fq;
+            if (HAS_PQ) pq_prev = L.pq;
+            Xe_cur = Xe_next;
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) cur[u] = nxt[u];
+    };
+    group(0);
+    for (int tb = U; tb < nsteps; tb += U) group(tb);
+}
+
+template <int KIND, bool HAS_PQ, bool PRO>
+__global__ __launch_bounds__(256) void k_mg_pair(MgPairArgs a, int RI, int nSG, int nRC) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int total = nSG * nRC, bid = blockIdx.x;
+    const int q8 = total >> 3, rem = total & 7, xcd = bid & 7, k8 = bid >> 3;   // XCD-aware tile order (see apply_tile)
+    const int logical = (xcd < rem) ? xcd * (q8 + 1) + k8 : rem * (q8 + 1) + (xcd - rem) * q8 + k8;
+    const int rc = logical / nSG;
+    const int sg = logical - rc * nSG;
+    Relax2Tile t;
+    t.c0 = (sg * 4 + wave) * 60;
+    t.c = t.c0 - 2 + lane;
+    t.out_lane = (lane >= 2) && (lane <= 61) && (t.c >= 1) && (t.c <= a.nj - 2);
+    t.i0 = 1 + rc * RI;
+    t.i1 = min(t.i0 + RI, a.ni - 1);
+    if (t.c0 <= a.nj - 2 && t.i0 < t.i1) mg_pair_strip<KIND, HAS_PQ, PRO, 3>(a, t);   // wave-uniform
+}
+
+bool mg_pair_supported(int ni, int nj) { return ni >= 5 && nj >= 5 && nj <= (1 << 20); }
+hipError_t launch_mg_pair(const MgPairArgs& a, int kind, hipStream_t st) {
+    if (!mg_pair_supported(a.ni, a.nj)) return hipErrorInvalidValue;
+    const int nstrips = (a.nj - 1 + 59) / 60, nSG = (nstrips + 3) / 4, interior = a.ni - 2;
+    int RI = 18;   // like K2x2: short chunks, and shorter still while the level cannot fill the device
+    while (RI > 3 && static_cast<long>(nSG) * ((interior + RI - 1) / RI) < 1024) RI -= 3;
+    RI = std::max(1, std::min(RI, interior));
+    const int nRC = (interior + RI - 1) / RI;
+    const dim3 grid(nSG * nRC), block(256);
+    const bool pq = a.pq != nullptr, pro = a.coarse != nullptr;
+    if (kind == 1) {
+        if (pq) hipLaunchKernelGGL((k_mg_pair<1, true, false>), grid, block, 0, st, a, RI, nSG, nRC);
+        else hipLaunchKernelGGL((k_mg_pair<1, false, false>), grid, block, 0, st, a, RI, nSG, nRC);
+    } else if (pro) {
+        if (pq) hipLaunchKernelGGL((k_mg_pair<0, true, true>), grid, block, 0, st, a, RI, nSG, nRC);
+        else hipLaunchKernelGGL((k_mg_pair<0, false, true>), grid, block, 0, st, a, RI, nSG, nRC);
+    } else {
+        if (pq) hipLaunchKernelGGL((k_mg_pair<0, true, false>), grid, block, 0, st, a, RI, nSG, nRC);
+        else hipLaunchKernelGGL((k_mg_pair<0, false, false>), grid, block, 0, st, a, RI, nSG, nRC);
+    }
+    return hipGetLastError();
+}
+
 static int g_fuse_rows = 0;   // 0 = choose per block (relax2_rows_per_chunk); > 0 = forced (tm_tune_fuse)
 constexpr int R2_U = 3;      // rows per load group of k_relax2
 

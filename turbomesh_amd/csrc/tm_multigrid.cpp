@@ -45,6 +45,7 @@ void BlockMG::build(DeviceArena& arena, int ni, int nj, bool has_pq, double aspe
         fuse_prolong = std::atoi(e) != 0;
         fuse_prolong_min = std::atoi(e) == 2 ? 0 : fuse_prolong_min;
     }
+    if (const char* e = std::getenv("TM_MG_PAIR")) use_pair = std::atoi(e) != 0;   // 0: the one-sweep-per-pass kernels everywhere (A/B runs, bit-identity tests)
     L.clear();
     MgLevel l0;
     l0.ni = ni;
@@ -138,7 +139,11 @@ void BlockMG::vcycle(const double2* f0, double2* z, double2* w0, double2* w1, hi
     std::vector<const double2*> rhs(nl, nullptr);
     // fine level: the last post-sweep must land in z; count the ping-pongs after the initial scaling
     const int pre_extra = nu_pre > 0 ? nu_pre - 1 : 0;
-    const int flips0 = (nl == 1) ? pre_extra + nu_coarsest : pre_extra + nu_post;
+    // pair(l): the level runs its two pre-sweeps + residual, and its two post-sweeps (+ prolongation), as ONE pass each (k_mg_pair)
+    auto pair_ok = [&](size_t l) { return use_pair && mg_pair_supported(L[l].ni, L[l].nj); };
+    const bool pair_pre0 = pair_ok(0) && nu_pre == 2 && nl > 1, pair_post0 = pair_ok(0) && nu_post == 2;
+    (void)pair_pre0;   // one flip either way
+    const int flips0 = (nl == 1) ? pre_extra + nu_coarsest : pre_extra + (pair_post0 ? 1 : nu_post);
     cur[0] = (flips0 % 2 == 0) ? z : w0;
     oth[0] = (flips0 % 2 == 0) ? w0 : z;
     rhs[0] = f0;
@@ -159,6 +164,21 @@ void BlockMG::vcycle(const double2* f0, double2* z, double2* w0, double2* w1, hi
         if (l == 0) {   // the two fine iterates are the caller's: make their perimeters zero (the coarse ones stay zero for good)
             HIPCHK(launch_copy_perimeter(w1, cur[0], L[0].ni, L[0].nj, st));
             HIPCHK(launch_copy_perimeter(w1, oth[0], L[0].ni, L[0].nj, st));
+        }
+        if (nu_pre == 2 && l + 1 < nl && pair_ok(l)) {   // both pre-sweeps AND the residual behind them in one pass over f
+            MgPairArgs a;
+            a.in = rhs[l];
+            a.xk = L[l].X;
+            a.pq = L[l].PQ;
+            a.out = oth[l];
+            a.out2 = L[l].r;
+            a.ni = L[l].ni;
+            a.nj = L[l].nj;
+            a.omega = omega;
+            HIPCHK(launch_mg_pair(a, 1, st));
+            std::swap(cur[l], oth[l]);
+            HIPCHK(launch_mg_restrict(L[l].r, L[l + 1].X, L[l + 1].f, pair(l), st));
+            continue;
         }
         if (nu_pre >= 2) {   // sweeps 1 and 2 from e = 0 in one pass over f (K2, MODE_MG_FIRST2); it lands where scale + one sweep would
             ApplyBlock a;
@@ -187,6 +207,26 @@ void BlockMG::vcycle(const double2* f0, double2* z, double2* w0, double2* w1, hi
     }
     // ---- up
     for (size_t l = nl - 1; l-- > 0;) {
+        if (nu_post == 2 && pair_ok(l)) {   // prolongation + both post-sweeps in one pass
+            MgPairArgs a;
+            a.in = cur[l];
+            a.xk = L[l].X;
+            a.pq = L[l].PQ;
+            a.f = rhs[l];
+            a.out = oth[l];
+            a.coarse = cur[l + 1];
+            const MgPair g = pair(l);
+            a.nic = g.nic;
+            a.njc = g.njc;
+            a.ci = g.ci;
+            a.cj = g.cj;
+            a.ni = L[l].ni;
+            a.nj = L[l].nj;
+            a.omega = omega;
+            HIPCHK(launch_mg_pair(a, 0, st));
+            std::swap(cur[l], oth[l]);
+            continue;
+        }
         // (levels of a few hundred thousand nodes and more: below that both forms are launch-bound and the plain pair is as fast)
         if (fuse_prolong && nu_post >= 1 && static_cast<int64_t>(L[l].ni) * L[l].nj >= fuse_prolong_min) {
             // the correction is interpolated as the rows of the iterate enter the first post-smoothing sweep's window (the same
