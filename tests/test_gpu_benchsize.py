@@ -257,3 +257,24 @@ def test_o4h_json_as_written_all_ten_iterations_with_default_options(name):
     assert all(r <= b for r, b in zip(rms, bound)), (rms, bound)
     if name == "LS89":
         assert max(bound) == 1e-10
+
+
+def test_k2x2_lone_2048_block_both_store_policies(monkeypatch):
+    # BASELINE configs[3]'s per-GPU shape: ONE 2048^2 block (64 MiB per field).  At this footprint K2x2 stores its results with the
+    # plain cache policy (the next pass finds them in the Infinity Cache), at 4096^2 and beyond with the streaming one
+    # (Smoother::relax2_store_nt): same arithmetic either way -- bit-identical to each other, to single sweeps and to the oracle's mirror
+    n = 2048
+    seed = configs.single_block(n, n, perturb=0.25)
+    x0 = seed.blocks[0].points.data.copy()
+    out = {}
+    for policy in ("0", "1"):
+        monkeypatch.setenv("TM_R2_STORE_NT", policy)
+        out[policy] = _history(copy.deepcopy(seed), False, [2, 5])
+    monkeypatch.delenv("TM_R2_STORE_NT")
+    single = _history(copy.deepcopy(seed), True, [2, 5])
+    default = _history(copy.deepcopy(seed), False, [2, 5])
+    for k in range(2):
+        assert np.array_equal(out["0"][k][0][0], out["1"][k][0][0])
+        assert np.array_equal(out["0"][k][0][0], single[k][0][0])
+        assert np.array_equal(default[k][0][0], single[k][0][0])
+    _check_windows(x0, default[0][0][0], [(slice(700, 771), slice(1000, 1135)), (slice(0, 70), slice(0, 131)), (slice(n - 64, n), slice(n - 133, n))], 2)

@@ -87,6 +87,7 @@ struct Relax2Block {
     double* partials;   // [nwg * MAX_PARTIALS]: sum (X^(k+2) - X^(k+1))^2 over interior rows
     const int32_t* border;   // tile ids of the BORDER workgroups (relax2_border_tiles), device array
     int nborder;
+    int store_nt = 1;   // result stores: 1 = streaming (nt), 0 = plain -- chosen by the handle from its footprint (launch_relax2_block)
     int dyn;            // sides whose perimeter values change from sweep to sweep (bit 0: i = 0, 1: i = ni-1, 2: j = 0, 3: j = nj-1);
                         // along the other sides `mid` holds constants, and workgroups touching only those count as INSIDE
 };

@@ -599,6 +599,9 @@ struct Relax2Tile {
     bool out_lane;       // lanes 2..61 on interior columns: store s2 (and the ring of s1)
 };
 
+#ifndef TM_R2_SAUX
+#define TM_R2_SAUX 2   // cache policy of K2x2's result stores: 2 = nt (streaming); experiment builds override it (tools/dev/ab_saux.sh)
+#endif
 constexpr unsigned OOB_VOFFSET = 0x80000000u;   // beyond num_records of every buffer resource below: the hardware drops the lane's store
 
 typedef int v4i32 __attribute__((ext_vector_type(4)));
@@ -682,7 +685,7 @@ __device__ __forceinline__ void relax2_strip_edge(const Relax2Block& a, const Re
             const double2 o = relax_row<W1>(S[A0], S[A1], S[A2], a.omega, d2);
             const bool live = t.out_lane && (i >= t.i0) && (i < t.i1);
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, o), out_rsrc,
-                                                   static_cast<int>(live ? lane_off + static_cast<unsigned>((i - t.i0) * nj * 16) : OOB_VOFFSET), 0, (NT & 1) ? 2 : 0);
+                                                   static_cast<int>(live ? lane_off + static_cast<unsigned>((i - t.i0) * nj * 16) : OOB_VOFFSET), 0, (NT & 1) ? TM_R2_SAUX : 0);
             if (DOT == DOT_DELTA) {
                 if (!live) d2 = zero;
                 accumulate<DOT_DELTA>(acc, S[A1].c, o, d2);
@@ -753,7 +756,7 @@ __device__ __forceinline__ void relax2_strip_inside(const Relax2Block& a, const 
             acc[2] += o.x + o.y;   // diagnostic build: no stores
 #else
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, o), out_rsrc, static_cast<int>(voff + static_cast<unsigned>((tb + u) * nj * 16)), 0,
-                                                   (NT & 1) ? 2 : 0);
+                                                   (NT & 1) ? TM_R2_SAUX : 0);
 #endif
             if (DOT == DOT_DELTA) {
                 if (!t.out_lane) d2 = make_double2(0.0, 0.0);   // masked lanes hold garbage (possibly non-finite): select, never multiply
@@ -1158,36 +1161,43 @@ std::vector<int32_t> relax2_border_tiles(int ni, int nj, int RI, int dyn) {
     }
     return ids;
 }
+// Launch dispatch over (partial sums, omega == 1, cache policy).  NTBITS: bit 0 = streaming (nt) result stores, bit 1 = streaming loads.
+// Result stores: streaming when the rank's fields are far larger than the 256 MB Infinity Cache or small enough for the L2s
+// (Relax2Block::store_nt, chosen by the handle from its footprint), plain in between -- a pass then finds the field the previous
+// pass wrote still in the Infinity Cache (lone 2048^2 block: 16.5 -> 14.2 us per sweep; 4096^2: streaming 111 us against 120 us per
+// pass; tools/dev/ab_saux.sh, tools/ubench/stream.hip).  Streaming loads: the capped interior pass of a multi-rank pair (lds > 0).
+#define TM_R2_DISPATCH(KERNEL, NTBITS, ...)                                                                                        \
+    do {                                                                                                                           \
+        if (dot == DOT_DELTA) {                                                                                                    \
+            if (w1) hipLaunchKernelGGL((KERNEL<DOT_DELTA, R2_U, NTBITS, true>), grid, block, lds, st, __VA_ARGS__);                 \
+            else hipLaunchKernelGGL((KERNEL<DOT_DELTA, R2_U, (NTBITS) & 1, false>), grid, block, lds, st, __VA_ARGS__);             \
+        } else {                                                                                                                   \
+            if (w1) hipLaunchKernelGGL((KERNEL<DOT_NONE, R2_U, NTBITS, true>), grid, block, lds, st, __VA_ARGS__);                  \
+            else hipLaunchKernelGGL((KERNEL<DOT_NONE, R2_U, (NTBITS) & 1, false>), grid, block, lds, st, __VA_ARGS__);              \
+        }                                                                                                                          \
+    } while (0)
 hipError_t launch_relax2_block(const Relax2Block& a, int RI, int dot, int subset, hipStream_t st, size_t lds, const QueueWait* wait) {
     const int nstrips = (a.nj - 1 + 59) / 60;
     const int nSG = (nstrips + 3) / 4, nRC = relax2_nchunks(a.ni, RI);
     if (subset == R2_BORDER && a.nborder == 0) return wait ? launch_queue_wait(wait->counter, wait->target, wait->error, st) : hipSuccess;
     const dim3 grid(subset == R2_BORDER ? a.nborder : nSG * nRC), block(256);
     const bool w1 = a.omega == 1.0;
+    const bool nts = a.store_nt != 0;
     if (wait) {
         const QueueWait w = *wait;
-        if (dot == DOT_DELTA) {
-            if (w1) hipLaunchKernelGGL((k_relax2_waited<DOT_DELTA, R2_U, 1, true>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
-            else hipLaunchKernelGGL((k_relax2_waited<DOT_DELTA, R2_U, 1, false>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
-        } else {
-            if (w1) hipLaunchKernelGGL((k_relax2_waited<DOT_NONE, R2_U, 1, true>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
-            else hipLaunchKernelGGL((k_relax2_waited<DOT_NONE, R2_U, 1, false>), grid, block, lds, st, a, RI, nSG, nRC, subset, w);
-        }
+        if (nts) TM_R2_DISPATCH(k_relax2_waited, 1, a, RI, nSG, nRC, subset, w);
+        else TM_R2_DISPATCH(k_relax2_waited, 0, a, RI, nSG, nRC, subset, w);
         return hipGetLastError();
     }
     // lds > 0 = the capped interior pass of a multi-rank sweep pair on a small block: streaming loads (relax2_strip_inside)
-    if (lds > 0 && w1) {
-        if (dot == DOT_DELTA) hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, 3, true>), grid, block, lds, st, a, RI, nSG, nRC, subset);
-        else hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, 3, true>), grid, block, lds, st, a, RI, nSG, nRC, subset);
+    static const int inside_ntl = [] { const char* e = std::getenv("TM_R2_INSIDE_NTL"); return e ? std::atoi(e) : -1; }();   // experiment knob
+    if (lds > 0 && w1 && (inside_ntl < 0 || inside_ntl == 1)) {
+        if (nts) TM_R2_DISPATCH(k_relax2, 3, a, RI, nSG, nRC, subset);
+        else TM_R2_DISPATCH(k_relax2, 2, a, RI, nSG, nRC, subset);
         return hipGetLastError();
     }
-    if (dot == DOT_DELTA) {
-        if (w1) hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, 1, true>), grid, block, lds, st, a, RI, nSG, nRC, subset);
-        else hipLaunchKernelGGL((k_relax2<DOT_DELTA, R2_U, 1, false>), grid, block, lds, st, a, RI, nSG, nRC, subset);
-    } else {
-        if (w1) hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, 1, true>), grid, block, lds, st, a, RI, nSG, nRC, subset);
-        else hipLaunchKernelGGL((k_relax2<DOT_NONE, R2_U, 1, false>), grid, block, lds, st, a, RI, nSG, nRC, subset);
-    }
+    if (nts) TM_R2_DISPATCH(k_relax2, 1, a, RI, nSG, nRC, subset);
+    else TM_R2_DISPATCH(k_relax2, 0, a, RI, nSG, nRC, subset);
     return hipGetLastError();
 }
 hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, int subset, hipStream_t st, size_t lds, const QueueWait* wait) {
@@ -1198,6 +1208,7 @@ hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_c
         B.n = 0;
         int total = 0;
         bool w1 = true;
+        const bool nts = blocks[first].store_nt != 0;   // one policy per handle
         for (int k = first; k < n && B.n < APPLY_BATCH_MAX; ++k) {
             const int q = B.n++;
             B.b[q] = blocks[k];
@@ -1214,37 +1225,22 @@ hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_c
         if (wait && !waited) {
             waited = true;
             const QueueWait w = *wait;
-            if (dot == DOT_DELTA) {
-                if (w1) hipLaunchKernelGGL((k_relax2_batch_waited<DOT_DELTA, R2_U, 1, true>), grid, block, lds, st, B, subset, w);
-                else hipLaunchKernelGGL((k_relax2_batch_waited<DOT_DELTA, R2_U, 1, false>), grid, block, lds, st, B, subset, w);
-            } else {
-                if (w1) hipLaunchKernelGGL((k_relax2_batch_waited<DOT_NONE, R2_U, 1, true>), grid, block, lds, st, B, subset, w);
-                else hipLaunchKernelGGL((k_relax2_batch_waited<DOT_NONE, R2_U, 1, false>), grid, block, lds, st, B, subset, w);
-            }
-            const hipError_t rc = hipGetLastError();
-            if (rc != hipSuccess) return rc;
-            continue;
-        }
-        if (lds > 0 && w1) {   // see launch_relax2_block
-            if (dot == DOT_DELTA) hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, 3, true>), grid, block, lds, st, B, subset);
-            else hipLaunchKernelGGL((k_relax2_batch<DOT_NONE, R2_U, 3, true>), grid, block, lds, st, B, subset);
-            const hipError_t e = hipGetLastError();
-            if (e != hipSuccess) return e;
-            continue;
-        }
-        if (dot == DOT_DELTA) {
-            if (w1) hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, 1, true>), grid, block, lds, st, B, subset);
-            else hipLaunchKernelGGL((k_relax2_batch<DOT_DELTA, R2_U, 1, false>), grid, block, lds, st, B, subset);
+            if (nts) TM_R2_DISPATCH(k_relax2_batch_waited, 1, B, subset, w);
+            else TM_R2_DISPATCH(k_relax2_batch_waited, 0, B, subset, w);
+        } else if (lds > 0 && w1) {   // see launch_relax2_block
+            if (nts) TM_R2_DISPATCH(k_relax2_batch, 3, B, subset);
+            else TM_R2_DISPATCH(k_relax2_batch, 2, B, subset);
         } else {
-            if (w1) hipLaunchKernelGGL((k_relax2_batch<DOT_NONE, R2_U, 1, true>), grid, block, lds, st, B, subset);
-            else hipLaunchKernelGGL((k_relax2_batch<DOT_NONE, R2_U, 1, false>), grid, block, lds, st, B, subset);
+            if (nts) TM_R2_DISPATCH(k_relax2_batch, 1, B, subset);
+            else TM_R2_DISPATCH(k_relax2_batch, 0, B, subset);
         }
-        const hipError_t e = hipGetLastError();
-        if (e != hipSuccess) return e;
+        const hipError_t rc = hipGetLastError();
+        if (rc != hipSuccess) return rc;
     }
     if (wait && !waited) return launch_queue_wait(wait->counter, wait->target, wait->error, st);   // nothing to launch: the wait alone
     return hipSuccess;
 }
+#undef TM_R2_DISPATCH
 void tune_fuse_rows(int rows) { g_fuse_rows = rows > 0 ? rows : 0; }
 
 // Rows per chunk of K2.  A block that cannot fill the device is bound by the chain of dependent row-group loads in each wave

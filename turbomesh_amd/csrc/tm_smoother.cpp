@@ -233,12 +233,20 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     for (int64_t b = 0; b < topo.nblocks(); ++b)
         if (has_hooks || owner[b] == lp.rank) fuse_pairs = fuse_pairs && relax2_supported(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
     if (fuse_pairs) M = vec();
+    {   // K2x2's result stores (launch_relax2_block): plain while the rank's field is a good fraction of the 256 MB Infinity Cache but not
+        // more than it holds beside the field being read -- measured crossovers: 1024^2 (16 MiB) streaming, 1448^2 .. 2896^2 plain, 4096^2 streaming
+        const double mib = 16.0 * static_cast<double>(lp.n_owned) / (1024.0 * 1024.0);
+        relax2_store_nt = !(mib > 24.0 && mib <= 160.0);
+        if (const char* e = std::getenv("TM_R2_STORE_NT")) relax2_store_nt = std::atoi(e) != 0;
+    }
     // Interior pass of a multi-rank sweep pair: when the chain through the border (perimeter rows -> border workgroups -> perimeter
     // rows -> exchange) is longer than the interior pass -- blocks of a few million nodes -- its short kernels must not queue for
     // wave slots: at the START of an interior pass every slot is taken and none is given back for ~10 us.  Asking for a third of
     // the CU's 160 KB of LDS caps the interior pass at 3 workgroups per CU (its registers allow 4): 19.9 -> 18.2 us per sweep at
     // 2048^2; at 4096^2 the interior pass is the longer one and the cap costs 3 % (58.4 -> 60.3), so it is not applied there.
-    if (fuse_pairs && has_hooks && lp.n_owned <= 6 * 1024 * 1024) inside_lds = 54 * 1024;
+    // ... unless the fields live in the Infinity Cache (plain result stores, above): there the pass is not what starves the chain's
+    // kernels, and both the cap and its streaming loads cost more than they give (2048^2, rank 1 of 3: 18.2-19.1 -> 16.1-16.6 us per sweep)
+    if (fuse_pairs && has_hooks && lp.n_owned <= 6 * 1024 * 1024 && relax2_store_nt) inside_lds = 54 * 1024;
     if (const char* e = std::getenv("TM_INSIDE_LDS_KB")) inside_lds = static_cast<size_t>(std::max(0, std::atoi(e))) * 1024;
 
     // ---- perimeter rows -> device SoA with rank-local ids
@@ -884,10 +892,6 @@ int Smoother::picard_bicgstab(tm_stats& st) {
         // r = D^-1 (b - A U) ; r_hat = r ; p = v = 0
         apply(U, r, MODE_RESID, DOT_OUT2, nullptr, X, 0.0, fuse2 ? STEP_INIT2 : STEP_INIT);
         st.operator_sweeps += 1;
-        HIPCHK(hipMemcpyAsync(r_hat, r, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));
-        HIPCHK(hipMemsetAsync(p, 0, sizeof(double2) * n_local, stream));
-        HIPCHK(hipMemsetAsync(v, 0, sizeof(double2) * n_local, stream));
-        if (fuse2) HIPCHK(hipMemsetAsync(t, 0, sizeof(double2) * n_local, stream));   // the first pass multiplies it by omega = 0
         if (restarts == 0) {   // scaled nonlinear residual of this outer iteration
             flush_pending();
             HIPCHK(hipMemcpyAsync(h_S, S, sizeof(KrylovScalars), hipMemcpyDeviceToHost, stream));
@@ -899,6 +903,11 @@ int Smoother::picard_bicgstab(tm_stats& st) {
                 break;
             }
         }
+        // (behind the stop test: an outer iteration that finds its system already solved moves no vector at all)
+        HIPCHK(hipMemcpyAsync(r_hat, r, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));
+        HIPCHK(hipMemsetAsync(p, 0, sizeof(double2) * n_local, stream));
+        HIPCHK(hipMemsetAsync(v, 0, sizeof(double2) * n_local, stream));
+        if (fuse2) HIPCHK(hipMemsetAsync(t, 0, sizeof(double2) * n_local, stream));   // the first pass multiplies it by omega = 0
         bool breakdown = false;
         poll_open = false;
         while (it_total < opt.max_inner) {
@@ -1022,6 +1031,7 @@ void Smoother::relax2_launch(int subset, bool counts, int dot, hipStream_t on, c
         a.nj = static_cast<int>(topo.nj[b]);
         a.omega = opt.omega;
         a.dyn = dyn_mask[k];
+        a.store_nt = relax2_store_nt ? 1 : 0;
         a.border = border_ids[k];
         a.nborder = border_n[k];
         a.partials = partials + static_cast<size_t>(poff2[k]) * MAX_PARTIALS;

@@ -70,6 +70,7 @@ struct Smoother {
     void precondition(const double2* in, double2* out);
     double2* M = nullptr;           // X^(k+1) of a fused pair of relax sweeps (perimeter + first-interior ring only)
     bool fuse_pairs = false;
+    bool relax2_store_nt = true;     // K2x2 result stores streaming (nt) or plain: by the rank's footprint against the Infinity Cache (create())
     bool pair_sync_events = false;   // TM_PAIR_SYNC=events when the handle was created: multi-rank sweep pairs ordered by events, not device counters
     size_t inside_lds = 0;          // dynamic LDS of the interior pass of a multi-rank sweep pair (occupancy cap, see create())
     // perimeter rows
