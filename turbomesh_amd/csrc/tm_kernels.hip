@@ -2415,8 +2415,10 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_stream(double2* __restrict__ a, c
     }
 }
 hipError_t launch_stream(int kind, double2* a, const double2* b, const double2* c, double s, int64_t n, hipStream_t st) {
-    if (kind == 1) hipLaunchKernelGGL(k_stream<1>, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, a, b, c, s, n);
-    else hipLaunchKernelGGL(k_stream<0>, dim3(vec_nwg(n)), dim3(VEC_BLOCK), 0, st, a, b, c, s, n);
+    // one trip per thread (grid = n / (256 x 4)): the fastest of the shapes tried in tools/ubench/stream.hip on this part
+    const int64_t g = std::max<int64_t>(1, std::min<int64_t>((n + VEC_BLOCK * 4 - 1) / (VEC_BLOCK * 4), 1 << 20));
+    if (kind == 1) hipLaunchKernelGGL(k_stream<1>, dim3(static_cast<unsigned>(g)), dim3(VEC_BLOCK), 0, st, a, b, c, s, n);
+    else hipLaunchKernelGGL(k_stream<0>, dim3(static_cast<unsigned>(g)), dim3(VEC_BLOCK), 0, st, a, b, c, s, n);
     return hipGetLastError();
 }
 
