@@ -1,7 +1,7 @@
 #!/bin/bash
 # The probes behind the numbers DESIGN.md / README.md quote, in one run on the MI355X box (through gpurun, from the repo root):
 #   tools/measure_round.sh r02   ->  gpurun_out/<tag>_measurements.txt   (copy into profiles/)
-tag=${1:-r02}
+tag=${1:-r03}
 out=gpurun_out/${tag}_measurements.txt
 mkdir -p gpurun_out
 {

@@ -4,7 +4,7 @@
 # kernel-trace + stats of the bench command (two sweeps per pass, and --single-sweep), of the Krylov and multigrid paths, and the
 # two SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with tracing domains) that profiles/traffic.json is made from.
 set -u
-tag=${1:-r02}
+tag=${1:-r03}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
