@@ -252,6 +252,8 @@ def main():
     ap.add_argument("--nt", type=int, default=-1, help="K2 non-temporal stores 0/1 (tuning)")
     ap.add_argument("--single-sweep", action="store_true", help="one kernel pass per sweep (K2) instead of two sweeps per pass (K2x2)")
     ap.add_argument("--fuse-rows", type=int, default=0, help="K2x2 rows per chunk (tuning)")
+    ap.add_argument("--settle-ms", type=float, default=250.0,
+                    help="untimed sweeps of the same workload before the W warm-up steps, so that the timed region runs at settled clocks (0 = off)")
     ap.add_argument("--profile-every", type=int, default=PROFILE_EVERY, help="bracket every k-th launch of the dominant kernel with a hipEvent pair")
     args = ap.parse_args()
 
@@ -388,6 +390,8 @@ def main():
         sm = smooth.Smoother(mesh, relax_opt, stream=torch.cuda.current_stream().cuda_stream)
         workload = f"single synthetic {n}x{n} block, TFI seed, Laplace control function, fixed boundary (SURVEY 8d config 2)"
 
+    nodes_rank_est = n * n * len(owned)
+
     def barrier():
         torch.cuda.synchronize()
         if dist is not None:
@@ -399,8 +403,17 @@ def main():
     # has never met real RCCL kernels from several peers on its queue either: if it happens on ANY rank, all ranks re-create their
     # handles with the event-ordered schedule (TM_PAIR_SYNC=events, slower by ~10-25 % per pair) and the line says so.
     pair_sync = os.environ.get("TM_PAIR_SYNC", "counters") if coupled else None
+    # Settling.  The sweep runs at the board's power cap (1380 W of 1400 W, shader clock 2.0 of 2.4 GHz: tools/dev/clock_probe.py), and
+    # the power controller needs ~50 ms of load before the clock has settled (three sweeps per pass: 54.7 us per sweep in the first
+    # 10 ms, 43.5 from 50 ms on, tools/dev/ramp_probe.py) -- far longer than W + K steps of the driver's runs.  The SAME sweeps on the
+    # SAME handle therefore run untimed for ~0.25 s first (a count fixed by the workload's size, identical on every rank); W and
+    # K are what the flags say and the line reports the extra steps.  --settle-ms 0 turns it off.
+    est_us = 55.0 * nodes_rank_est / (4096.0 * 4096.0)
+    settle_steps = 0 if args.settle_ms <= 0 else max(60, min(60000, int(args.settle_ms * 1e3 / max(est_us, 0.5)) // 6 * 6))
     ok = 1
     try:
+        if settle_steps:
+            sm.iterate(settle_steps)
         sm.iterate(args.warmup)
         torch.cuda.synchronize()
     except _capi.TmError as e:
@@ -421,7 +434,7 @@ def main():
         mesh = tmd.strip_for_rank(world, rank, n, n, blocks_per_rank=bpr)
         hooks_obj = make_coupled_handle()
         sm = hooks_obj.smoother
-        sm.iterate(args.warmup)
+        sm.iterate(settle_steps + args.warmup)
         pair_sync = "events (fallback: a device-side wait of the counter-ordered schedule timed out during warm-up)"
     sm.profile(max(1, args.profile_every))
     barrier()
@@ -444,12 +457,14 @@ def main():
         if rank == 0:
             whole = configs.strip(nblocks_total, n, n)
             with smooth.Smoother(whole, relax_opt) as ref:
+                if settle_steps:
+                    ref.iterate(settle_steps)
                 ref.iterate(args.warmup)
                 ref.iterate(args.steps)
                 ref.download()
             got = np.concatenate([p.cpu().numpy() for p in parts])
             verified = all(np.array_equal(got[b], whole.blocks[b].points.data) for b in range(nblocks_total))
-            print(f"[bench] --verify: {world} ranks vs one handle after {args.warmup}+{args.steps} sweeps: {'bit-identical' if verified else 'MISMATCH'}", file=sys.stderr)
+            print(f"[bench] --verify: {world} ranks vs one handle after {settle_steps}+{args.warmup}+{args.steps} sweeps: {'bit-identical' if verified else 'MISMATCH'}", file=sys.stderr)
 
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -463,6 +478,8 @@ def main():
         k2_avg_s = (k2_ms / 1e3) / max(1, k2_timed)
         sweeps_per_launch = st["operator_sweeps"] / max(1, k2_launches)   # one launch takes this rank's blocks through 1 (K2) or 2 (K2x2) sweeps
         fused = sweeps_per_launch > 1.5
+        spl = int(round(sweeps_per_launch))
+        kname = {1: "k_apply", 2: "k_relax2", 3: "k_relax3"}.get(spl, "k_relax2")
         # what ONE launch of the dominant kernel has to move: every owned node read once and written once, however many
         # sweeps it performs on the way (K2x2: two).  achieved / peak is therefore a true bandwidth fraction, <= 1.
         bytes_per_launch = BYTES_PER_NODE * nodes_rank
@@ -472,7 +489,7 @@ def main():
         if os.path.exists(tpath) and args.config == 2 and world == 1:
             try:
                 tj = json.load(open(tpath))
-                if tj.get("n") == n and tj.get("kernel", "k_apply") == ("k_relax2" if fused else "k_apply"):
+                if tj.get("n") == n and tj.get("kernel", "k_apply") == kname:
                     stale = tj.get("kernels_hash") not in (None, kernels_hash())
                     traffic = None if stale else tj.get("hbm_bytes_per_launch")
                     traffic_src = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of an earlier run of this command"
@@ -495,7 +512,9 @@ def main():
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "nodes_total": nodes_total, "nodes_per_gpu": nodes_rank,
-                       "solver": "hip/relax (fused Jacobi elliptic sweep" + (", two sweeps per kernel pass)" if fused else ")"), "omega": 1.0,
+                       "solver": "hip/relax (fused Jacobi elliptic sweep" + (f", {spl} sweeps per kernel pass)" if fused else ")"), "omega": 1.0,
+                       "settle": {"steps": settle_steps, "why": "untimed sweeps of the same workload before the W warm-up steps: the pass runs at the board power cap and "
+                                  "the clock needs ~50 ms of load to settle (tools/dev/ramp_probe.py); --settle-ms 0 turns it off"},
                        "residual_last": st["last_residual"], **({"verified_against_single_handle": verified} if verified is not None else {}),
                        **({"pair_sync": pair_sync} if pair_sync else {}),
                        "sweep_equiv_GBps_whole_job": BYTES_PER_NODE * value / 1e9},
@@ -505,11 +524,14 @@ def main():
                          "frac_of_stream": (achieved / max(stream.values()) if stream else None),
                          "stream": ({**stream, "what": f"tm_stream_probe in this run: copy / triad of {16 * nodes_rank / 2**20:.0f} MiB per array, non-temporal 16 B/lane, 20 launches each"}
                                     if stream else None),
-                         "kernel": "k_relax2<DELTA> (K2x2: two winslow sweeps per launch)" if fused else "k_apply<RELAX,DELTA,field,laplace> (K2 winslow_apply)",
+                         "kernel": (f"{kname}<DELTA> (K2x{spl}: {spl} winslow sweeps per launch)" if fused else "k_apply<RELAX,DELTA,field,laplace> (K2 winslow_apply)"),
+                         "limited_by": ("fp64 issue under the board power cap (1380 W of 1400 W, shader clock 2.0 of 2.4 GHz while the pass runs: tools/dev/clock_probe.py); "
+                                        "more sweeps per pass trade HBM bytes for nothing but the arithmetic the sweeps need anyway, so `frac` falls while nodes/s rise"
+                                        if fused else "HBM"),
                          "sweeps_per_launch": sweeps_per_launch, "bytes_per_launch": bytes_per_launch,
                          "bytes_model": "32 B per owned node per LAUNCH: the field is read once and written once per pass (rank 0's blocks)",
                          "sweep_equiv_GBps": BYTES_PER_NODE * nodes_rank * sweeps_per_launch / k2_avg_s / 1e9,
-                         "sweep_equiv_note": ("SURVEY 8d counts 32 B per node per SWEEP; a temporally blocked pass performs two sweeps for one read + one write, "
+                         "sweep_equiv_note": ("SURVEY 8d counts 32 B per node per SWEEP; a temporally blocked pass performs several sweeps for one read + one write, "
                                               "so this figure may exceed the HBM peak -- it is not a bandwidth") if fused else "one sweep per launch: equals achieved",
                          "hbm_GBps_measured_traffic": (traffic / k2_avg_s / 1e9) if traffic else None,
                          "avg_launch_us": k2_avg_s * 1e6, "launches": k2_launches, "launches_timed": k2_timed,

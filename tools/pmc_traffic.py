@@ -5,7 +5,7 @@
 gfx950 corrections applied as that guide prescribes: FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE reports exactly
 half of the bytes of a wide (16 B/lane) coalesced streaming read -> doubled; WRITE_SIZE is exact for 16 B/lane streaming stores.
 
-usage: pmc_traffic.py <dir with FETCH_SIZE run> <dir with WRITE_SIZE run> <n> <out.json> [kernel substring = k_relax2] [sweeps per launch = 2]"""
+usage: pmc_traffic.py <dir with FETCH_SIZE run> <dir with WRITE_SIZE run> <n> <out.json> [kernel substring = k_relax3] [sweeps per launch = 3]"""
 import csv
 import datetime
 import glob
@@ -29,8 +29,8 @@ def mean_duration_us(d, kernel="k_apply"):
 
 if __name__ == "__main__":
     dfetch, dwrite, n, out = sys.argv[1], sys.argv[2], int(sys.argv[3]), sys.argv[4]
-    kern = sys.argv[5] if len(sys.argv) > 5 else "k_relax2"
-    spl = int(sys.argv[6]) if len(sys.argv) > 6 else (2 if kern == "k_relax2" else 1)
+    kern = sys.argv[5] if len(sys.argv) > 5 else "k_relax3"
+    spl = int(sys.argv[6]) if len(sys.argv) > 6 else {"k_relax2": 2, "k_relax3": 3}.get(kern, 1)
     fetch_kib, nf = mean_counter(dfetch, "FETCH_SIZE", kern)
     write_kib, nw = mean_counter(dwrite, "WRITE_SIZE", kern)
     read_bytes = 2.0 * fetch_kib * 1024.0

@@ -119,6 +119,11 @@ struct Relax2Batch {
 hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, int subset, hipStream_t stream,
                                 size_t lds_bytes = 0, const QueueWait* wait = nullptr);
 void tune_fuse_rows(int rows);
+// ---- K2x3: THREE fused sweeps per pass of blocks whose perimeter rows are all `fixed` (in -> out; `mid`, `border`, `dyn` unused)
+bool relax3_supported(int ni, int nj);
+int relax3_rows_per_chunk(int ni, int nj);
+int relax3_block_nwg(int ni, int nj, int rows_per_chunk);
+hipError_t launch_relax3_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, hipStream_t stream);
 
 // ---- K4/K5 perimeter rows.  The rows of an interface are REGULAR: along a connection the row id, every column id and the
 // four metric neighbours advance by constant strides while kind, column count, stencil slots and static coefficients stay

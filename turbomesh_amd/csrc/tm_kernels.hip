@@ -907,6 +907,186 @@ __global__ __launch_bounds__(256) void k_relax2_batch(Relax2Batch B, int subset)
 }
 
 // ------------------------------------------------------------------------------------------
+// K2x3: THREE fused Jacobi sweeps per pass, for blocks whose perimeter rows are all `fixed` (a single block with prescribed
+// walls: BASELINE configs[1], the slices of configs[4]).  K2x2 is within ~10 % of what the part streams for its traffic
+// (tools/ubench/stream.hip) while its fp64 pipes idle a third of the time; a third sweep per pass costs arithmetic only.  With the
+// perimeter constant, the perimeter value of every intermediate field is the input's own value at that node, so no `mid` array,
+// no ring and no perimeter-row kernel take part.  A wave loads the 64 columns c0-H .. c0+63-H and owns the 64-2H output columns
+// c0 .. c0+63-2H (H = 4: 56 columns, every stored segment a whole number of 64 B sectors; three sweeps need 3); row chunks overlap
+// by 3 rows either side.  Same arithmetic as three K2 launches, bit for bit (tests/test_gpu_fused.py, test_gpu_benchsize.py).
+// ------------------------------------------------------------------------------------------
+#ifndef TM_R3_WAVES
+#define TM_R3_WAVES 1
+#endif
+constexpr int R3_U = 3;                 // rows per load group
+constexpr int R3_H = 4;                 // halo lanes per side
+constexpr int R3_W = 64 - 2 * R3_H;     // output columns per wave
+template <int DOT, int U, int NT, bool W1, bool INSIDE>
+__device__ __forceinline__ void relax3_strip(const Relax2Block& a, const Relax2Tile& t, double (&acc)[MAX_PARTIALS]) {
+    const int ni = a.ni, nj = a.nj;
+    const int cc = INSIDE ? t.c : min(max(t.c, 0), nj - 1);
+    const double2* in_col = a.in + cc;
+    const int last_row = INSIDE ? t.i1 + 2 : ni - 1;
+    auto load_in = [&](int row) { return in_col[static_cast<size_t>(INSIDE ? min(row, last_row) : min(max(row, 0), last_row)) * nj]; };
+    const bool perim_col = !INSIDE && ((t.c <= 0) || (t.c >= nj - 1));
+    const int nrows = t.i1 - t.i0;
+    const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + static_cast<size_t>(t.i0) * nj, 0, nrows * nj * 16, 0x00020000);
+    const unsigned lane_off = t.out_lane ? static_cast<unsigned>(cc) * 16u : OOB_VOFFSET;
+    const double2 zero = make_double2(0.0, 0.0);
+
+    Row3 A[3], S1[3], S2[3];
+    double2 pc[U], pn[U];
+    {   // rows i0-3, i0-2 are in the window before the first step (which takes row i0-1)
+        const double2 a0 = load_in(t.i0 - 3), a1 = load_in(t.i0 - 2);
+#pragma unroll
+        for (int u = 0; u < U; ++u) pc[u] = load_in(t.i0 - 1 + u);
+        A[0] = make_row(a0);
+        A[1] = make_row(a1);
+        A[2].c = A[2].e = A[2].h = zero;
+        S1[0] = S1[1] = S1[2] = A[2];
+        S2[0] = S2[1] = S2[2] = A[2];
+    }
+    // step s takes row r = i0 - 1 + s of the input, forms s1[r-1], s2[r-2], s3[r-3] and stores row r-3; s3 is live from s = 4 on
+    const int nsteps = nrows + 4;
+    auto group = [&](const int tb) {
+#pragma unroll
+        for (int u = 0; u < U; ++u) pn[u] = load_in(t.i0 - 1 + tb + U + u);
+#pragma unroll
+        for (int u = 0; u < U; ++u) {
+            const int A0 = u % 3, A1 = (u + 1) % 3, A2 = (u + 2) % 3;   // window slots of rows r-2, r-1, r (and of the same offsets one / two levels up)
+            const int r = t.i0 - 1 + tb + u;
+            A[A2] = make_row(pc[u]);
+            double2 d = zero;
+            double2 s1 = relax_row<W1>(A[A0], A[A1], A[A2], a.omega, d);          // row r-1
+            if (!INSIDE && (perim_col || r - 1 <= 0 || r - 1 >= ni - 1)) s1 = A[A1].c;   // fixed: the input's own value
+            S1[A2] = make_row(s1);
+            double2 s2 = relax_row<W1>(S1[A0], S1[A1], S1[A2], a.omega, d);       // row r-2
+            if (!INSIDE && (perim_col || r - 2 <= 0 || r - 2 >= ni - 1)) s2 = S1[A1].c;
+            S2[A2] = make_row(s2);
+            double2 d3 = zero;
+            const double2 o = relax_row<W1>(S2[A0], S2[A1], S2[A2], a.omega, d3);   // row r-3
+            const int i = r - 3;
+            const bool row_live = (i >= t.i0) && (i < t.i1);   // wave-uniform
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, o), out_rsrc,
+                                                   static_cast<int>(row_live ? lane_off + static_cast<unsigned>((i - t.i0) * nj * 16) : OOB_VOFFSET), 0,
+                                                   (NT & 1) ? 2 : 0);
+            if (DOT == DOT_DELTA) {
+                if (!(t.out_lane && row_live)) d3 = zero;   // masked lanes hold garbage (possibly non-finite): select, never multiply
+                accumulate<DOT_DELTA>(acc, S2[A1].c, o, d3);
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < U; ++u) pc[u] = pn[u];
+    };
+    group(0);
+    for (int tb = U; tb < nsteps; tb += U) group(tb);
+}
+
+template <int DOT, int U, int NT, bool W1>
+__device__ __forceinline__ void relax3_tile(const Relax2Block& a, int RI, int nSG, int nRC, int bid) {
+    const int lane = threadIdx.x & 63;
+    const int wave = threadIdx.x >> 6;
+    const int total = nSG * nRC;
+    const int q8 = total >> 3, rem = total & 7, xcd = bid & 7, k8 = bid >> 3;
+    const int logical = (xcd < rem) ? xcd * (q8 + 1) + k8 : rem * (q8 + 1) + (xcd - rem) * q8 + k8;
+    const int rc = logical / nSG;
+    const int sg = logical - rc * nSG;
+    const int ni = a.ni, nj = a.nj;
+    Relax2Tile t;
+    t.c0 = (sg * 4 + wave) * R3_W;
+    t.c = t.c0 - R3_H + lane;
+    t.out_lane = (lane >= R3_H) && (lane < 64 - R3_H) && (t.c >= 1) && (t.c <= nj - 2);
+    t.i0 = 1 + rc * RI;
+    t.i1 = min(t.i0 + RI, ni - 1);
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    if (t.c0 <= nj - 2 && t.i0 < t.i1) {   // wave-uniform
+        // strictly inside: every column the wave loads within [1, nj-2] and every row it touches within [1, ni-2] -> no fixed value is
+        // ever selected, no index is clamped from below
+        const bool inside = (t.c0 - R3_H >= 1) && (t.c0 - R3_H + 63 <= nj - 2) && (t.i0 - 3 >= 1) && (t.i1 + 2 <= ni - 2);
+        if (inside) relax3_strip<DOT, U, NT, W1, true>(a, t, acc);
+        else relax3_strip<DOT, U, NT, W1, false>(a, t, acc);
+    }
+    if (DOT != DOT_NONE) block_partials<256, dot_columns(DOT)>(acc, a.partials + static_cast<size_t>(logical) * MAX_PARTIALS);
+}
+template <int DOT, int U, int NT, bool W1>
+__global__ __launch_bounds__(256, TM_R3_WAVES) void k_relax3(Relax2Block a, int RI, int nSG, int nRC) {
+    relax3_tile<DOT, U, NT, W1>(a, RI, nSG, nRC, blockIdx.x);
+}
+template <int DOT, int U, int NT, bool W1>
+__global__ __launch_bounds__(256) void k_relax3_batch(Relax2Batch B) {
+    int k = 0;
+#pragma unroll
+    for (int q = 1; q < APPLY_BATCH_MAX; ++q)
+        if (q < B.n && static_cast<int>(blockIdx.x) >= B.start[q]) k = q;
+    relax3_tile<DOT, U, NT, W1>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], static_cast<int>(blockIdx.x) - B.start[k]);
+}
+static int g_fuse3_rows = 0;   // experiments (TM_FUSE3_ROWS)
+int relax3_rows_per_chunk(int ni, int nj) {
+    static const int forced = [] { const char* e = std::getenv("TM_FUSE3_ROWS"); return e ? std::atoi(e) : 0; }();
+    const int interior = ni - 2;
+    if (forced > 0 || g_fuse3_rows > 0) return std::max(1, std::min(forced > 0 ? forced : g_fuse3_rows, interior));
+    // The pass is bound by fp64 issue under the power cap, not by bandwidth, so the rows a chunk recomputes for its neighbours
+    // ((3 RI + 6) / 3 RI of the arithmetic) count: tall chunks, as long as the launch still fills the device a little more than
+    // once (3 workgroups per CU at 134 registers).  Steady state, us per sweep (tools/dev/steady_time.py): 4096^2 18 rows 46.8,
+    // 24: 44.9, 36 .. 72: 43.5, 96: 45.9; 2048^2 12: 13.9, 18 .. 24: 13.35, 36: 14.0; 1024^2 12: 4.9, 24: 5.3, 36: 7.1.
+    static int slots = 0;
+    if (slots == 0) {
+        int dev = 0, cus = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
+        slots = 3 * cus;
+    }
+    const int nstrips = (nj - 1 + R3_W - 1) / R3_W, nSG = (nstrips + 3) / 4;
+    int RI = 36;
+    while (RI > 12 && static_cast<long>(nSG) * ((interior + RI - 1) / RI) * 10 < static_cast<long>(slots) * 11) RI -= 3;
+    return std::max(1, std::min(RI, interior));
+}
+bool relax3_supported(int ni, int nj) { return ni >= 7 && nj >= 7 && nj <= (1 << 20); }
+int relax3_block_nwg(int ni, int nj, int RI) {
+    const int nstrips = (nj - 1 + R3_W - 1) / R3_W;
+    return ((nstrips + 3) / 4) * ((ni - 2 + RI - 1) / RI);
+}
+hipError_t launch_relax3_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, hipStream_t st) {
+    for (int first = 0; first < n; first += APPLY_BATCH_MAX) {
+        Relax2Batch B;
+        B.n = 0;
+        int total = 0;
+        bool w1 = true;
+        const bool nts = blocks[first].store_nt != 0;
+        for (int k = first; k < n && B.n < APPLY_BATCH_MAX; ++k) {
+            const int q = B.n++;
+            B.b[q] = blocks[k];
+            B.RI[q] = rows_per_chunk[k];
+            B.nSG[q] = ((blocks[k].nj - 1 + R3_W - 1) / R3_W + 3) / 4;
+            B.nRC[q] = (blocks[k].ni - 2 + B.RI[q] - 1) / B.RI[q];
+            B.start[q] = total;
+            total += B.nSG[q] * B.nRC[q];
+            w1 = w1 && blocks[k].omega == 1.0;
+        }
+        for (int q = B.n; q < APPLY_BATCH_MAX; ++q) B.start[q] = total;
+        if (total == 0) continue;
+        const dim3 grid(total), block(256);
+#define TM_R3(KERNEL, ...)                                                                                                   \
+    do {                                                                                                                     \
+        if (dot == DOT_DELTA) {                                                                                              \
+            if (w1 && nts) hipLaunchKernelGGL((KERNEL<DOT_DELTA, R3_U, 1, true>), grid, block, 0, st, __VA_ARGS__);          \
+            else if (w1) hipLaunchKernelGGL((KERNEL<DOT_DELTA, R3_U, 0, true>), grid, block, 0, st, __VA_ARGS__);            \
+            else hipLaunchKernelGGL((KERNEL<DOT_DELTA, R3_U, 1, false>), grid, block, 0, st, __VA_ARGS__);                   \
+        } else {                                                                                                             \
+            if (w1 && nts) hipLaunchKernelGGL((KERNEL<DOT_NONE, R3_U, 1, true>), grid, block, 0, st, __VA_ARGS__);           \
+            else if (w1) hipLaunchKernelGGL((KERNEL<DOT_NONE, R3_U, 0, true>), grid, block, 0, st, __VA_ARGS__);             \
+            else hipLaunchKernelGGL((KERNEL<DOT_NONE, R3_U, 1, false>), grid, block, 0, st, __VA_ARGS__);                    \
+        }                                                                                                                    \
+    } while (0)
+        if (B.n == 1) TM_R3(k_relax3, B.b[0], B.RI[0], B.nSG[0], B.nRC[0]);
+        else TM_R3(k_relax3_batch, B);
+#undef TM_R3
+        const hipError_t rc = hipGetLastError();
+        if (rc != hipSuccess) return rc;
+    }
+    return hipSuccess;
+}
+
+// ------------------------------------------------------------------------------------------
 // Multigrid: TWO chained applications of a level's frozen-coefficient operator in ONE pass over the level -- the K2x2
 // structure (60-of-64 column strips, a 3-row window per stage in registers, rows requested one group ahead, lane / row
 // predicates folded into selects and out-of-range buffer-store offsets) applied to the error equation D^-1 A e = f:

@@ -454,8 +454,25 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         poff2_edge = off2;
         nwg_apply2 = off2 + edge_nf.nwg;
     }
+    // three sweeps per pass (K2x3): every perimeter row of every owned block `fixed` (nothing for a perimeter-row kernel to do, no
+    // neighbour to exchange with) -- a single block with prescribed walls, independent slices
+    fuse_triples = fuse_pairs && edge_nf.nrows == 0 && !(has_hooks && (!lp.send_ids.empty() || !lp.ghost_gid.empty()));
+    if (const char* e = std::getenv("TM_FUSE_3")) fuse_triples = fuse_triples && std::atoi(e) != 0;
+    if (fuse_triples) {
+        poff3.clear();
+        rows3.clear();
+        int off3 = 0;
+        for (int64_t b : lp.owned_blocks) {
+            const int bi = static_cast<int>(topo.ni[b]), bj = static_cast<int>(topo.nj[b]);
+            if (!relax3_supported(bi, bj)) fuse_triples = false;
+            poff3.push_back(off3);
+            rows3.push_back(relax3_rows_per_chunk(bi, bj));
+            off3 += relax3_block_nwg(bi, bj, rows3.back());
+        }
+        nwg_apply3 = off3;
+    }
     nwg_vec = vec_nwg(n_owned);
-    const uint64_t npart = static_cast<uint64_t>(std::max(std::max(nwg_apply, nwg_apply2), nwg_vec)) * MAX_PARTIALS;
+    const uint64_t npart = static_cast<uint64_t>(std::max(std::max(std::max(nwg_apply, nwg_apply2), fuse_triples ? nwg_apply3 : 0), nwg_vec)) * MAX_PARTIALS;
     // Krylov modes on a small single-process mesh: the scalar steps travel with the kernels that consume their result (LazyScalars,
     // tm_kernels.h) -- three partial-sum buffers in rotation, two scalar blocks
     lazy = !has_hooks && opt.inner != TM_INNER_RELAX && std::max(nwg_apply, nwg_vec) <= 512 && !(opt.flags & TM_OPT_EAGER_SCALARS);
@@ -1040,6 +1057,30 @@ void Smoother::relax2_launch(int subset, bool counts, int dot, hipStream_t on, c
     profiled([&]() { HIPCHK(launch_relax2_blocks(blocks.data(), rows2.data(), static_cast<int>(blocks.size()), dot, subset, on, lds, wait)); }, counts, on);
 }
 
+// Three sweeps in one pass (K2x3, all perimeter rows fixed): X^(k+3) = S(S(S(X^k))), bit-identical to three single sweeps
+void Smoother::relax_triple(bool want_partials) {
+    const int dot = want_partials ? DOT_DELTA : DOT_NONE;
+    std::vector<Relax2Block> blocks(lp.owned_blocks.size());
+    for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
+        const int64_t b = lp.owned_blocks[k];
+        const int64_t ls = lp.local_start[k];
+        Relax2Block& a = blocks[k];
+        a.in = X + ls;
+        a.mid = nullptr;
+        a.out = U + ls;
+        a.ni = static_cast<int>(topo.ni[b]);
+        a.nj = static_cast<int>(topo.nj[b]);
+        a.omega = opt.omega;
+        a.dyn = 0;
+        a.store_nt = relax2_store_nt ? 1 : 0;
+        a.border = nullptr;
+        a.nborder = 0;
+        a.partials = partials + static_cast<size_t>(poff3[k]) * MAX_PARTIALS;
+    }
+    profiled([&]() { HIPCHK(launch_relax3_blocks(blocks.data(), rows3.data(), static_cast<int>(blocks.size()), dot, stream)); }, true, stream);
+    std::swap(X, U);
+}
+
 // want_partials: only the pass whose displacement norms are read back pays for them (the last one of an iterate() call)
 void Smoother::relax_pair(bool want_partials) {
     const int dot = want_partials ? DOT_DELTA : DOT_NONE;
@@ -1178,16 +1219,25 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
 void Smoother::relax_sweeps(uint64_t n, tm_stats& st) {
     int last_nwg = nwg_apply;
     uint64_t k = 0;
-    if (fuse_pairs && n >= 2) {
-        const uint64_t npairs = n / 2;
-        if (has_hooks && (n_send > 0 || n_ghost > 0)) {
-            relax_pairs_pipelined(npairs, n % 2 == 0);
-        } else {
-            for (uint64_t q = 0; q < npairs; ++q) relax_pair(q + 1 == npairs && n % 2 == 0);
-        }
-        k = 2 * npairs;
+    if (fuse_triples && n >= 3) {   // n = 3 a + 2 b + c, as many triples as possible (n = 4: one triple + one single sweep)
+        const uint64_t ntriples = n / 3;
+        for (uint64_t q = 0; q < ntriples; ++q) relax_triple(q + 1 == ntriples && n % 3 == 0);
+        k = 3 * ntriples;
         st.operator_sweeps += k;
         outer_done += k;
+        last_nwg = nwg_apply3;
+    }
+    if (fuse_pairs && n - k >= 2) {
+        const uint64_t npairs = (n - k) / 2;
+        const bool last_is_pair = (n - k) % 2 == 0;
+        if (has_hooks && (n_send > 0 || n_ghost > 0)) {
+            relax_pairs_pipelined(npairs, last_is_pair);
+        } else {
+            for (uint64_t q = 0; q < npairs; ++q) relax_pair(q + 1 == npairs && last_is_pair);
+        }
+        k += 2 * npairs;
+        st.operator_sweeps += 2 * npairs;
+        outer_done += 2 * npairs;
         last_nwg = nwg_apply2;
     }
     for (; k < n; ++k) {

@@ -106,6 +106,9 @@ struct Smoother {
     int poff_edge = 0, nwg_apply = 0, nwg_vec = 0;
     std::vector<int> poff2, rows2;  // same for the fused two-sweep launches, and their rows per workgroup
     int poff2_edge = 0, nwg_apply2 = 0;
+    std::vector<int> poff3, rows3;  // ... and for the three-sweep launches (all perimeter rows fixed)
+    int nwg_apply3 = 0;
+    bool fuse_triples = false;
     // halo exchange
     int32_t* d_send_ids = nullptr;
     double2* d_send_buf = nullptr;
@@ -181,6 +184,7 @@ struct Smoother {
     int picard_bicgstab(tm_stats& st);
     void relax_sweeps(uint64_t n, tm_stats& st);
     void relax_pair(bool want_partials);
+    void relax_triple(bool want_partials);
     void profiled(const std::function<void()>& launch, bool counts = true, hipStream_t on = nullptr);
     void relax2_launch(int subset, bool counts, int dot, hipStream_t on = nullptr, const QueueWait* wait = nullptr);
 };
