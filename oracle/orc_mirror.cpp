@@ -43,6 +43,12 @@ static inline Vec2d mirror_row(int mode, bool has_pq, Vec2d m_l, Vec2d m_c, Vec2
     Float sx = G22 * ax, sy = G22 * ay;
     sx = std::fma(G11, bx, sx);
     sy = std::fma(G11, by, sy);
+    if (mode == MIRROR_RELAX && omega == 1.0) {   // the device's full Jacobi step: x_new = q / (2 D), q = 4 x the off-diagonal part of the row
+        const Float qx = std::fma(mhG12, kx, sx), qy = std::fma(mhG12, ky, sy);
+        if (D == 0.0) return c_c;                 // degenerate cell: every coefficient vanishes, the node stays
+        const Float r = 1.0 / m2D;
+        return vinit(-(qx * r), -(qy * r));
+    }
     sx = std::fma(m2D, c_c.data[0], sx);
     sy = std::fma(m2D, c_c.data[1], sy);
     sx = std::fma(mhG12, kx, sx);

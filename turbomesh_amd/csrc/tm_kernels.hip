@@ -213,6 +213,31 @@ __device__ __forceinline__ double2 winslow_row(double2 m_c, double2 e_m, double2
     double sx = G22 * ax, sy = G22 * ay;
     sx = fma(G11, bx, sx);
     sy = fma(G11, by, sy);
+    if (MODE == MODE_RELAX && (UNIT_OMEGA || omega == 1.0)) {
+        // A full Jacobi step in its textbook form x_new = (b - sum_{k != i} a_ik x_k) / a_ii = q / (2 D), q = 4 x the off-diagonal part of
+        // the row: the diagonal term and the "c + displacement" addition of the general form below cancel analytically, which
+        // saves 4 of ~52 fp64 operations per node and sweep -- and the sweep is bound by fp64 issue under the board's power cap
+        // (DESIGN.md section 4).  The oracle's mirror makes the same step (oracle/orc_mirror.cpp); omega != 1 keeps the general form.
+        const double qx = fma(mhG12, kx, sx), qy = fma(mhG12, ky, sy);
+        const bool plain = (D >= 0x1p-700) && (D <= 0x1p700);   // see recip_diag
+        double2 xn;
+        if (__builtin_amdgcn_ballot_w64(!plain) == 0) {
+            const double nd = -m2D;
+            const double r0 = __builtin_amdgcn_rcp(m2D);
+            const double e0 = fma(nd, r0, 1.0);
+            const double r1 = fma(r0, e0, r0);
+            const double e1 = fma(nd, r1, 1.0);
+            const double r2 = fma(r1, e1, r1);
+            const double e2 = fma(nd, r2, 1.0);
+            const double r = fma(e2, r2, r2);   // 1 / (-2 D), correctly rounded
+            xn = make_double2(-(qx * r), -(qy * r));
+        } else {   // a degenerate cell (all coefficients vanish: the row reads 0 = 0, the node stays) or extreme spacings
+            const double r = 1.0 / m2D;
+            xn = (D == 0.0) ? c_c : make_double2(-(qx * r), -(qy * r));
+        }
+        delta = make_double2(xn.x - c_c.x, xn.y - c_c.y);
+        return xn;
+    }
     sx = fma(m2D, c_c.x, sx);
     sy = fma(m2D, c_c.y, sy);
     sx = fma(mhG12, kx, sx);
