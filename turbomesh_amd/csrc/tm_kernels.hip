@@ -937,14 +937,14 @@ __global__ __launch_bounds__(256) void k_relax2_batch(Relax2Batch B, int subset)
 // (tools/ubench/stream.hip) while its fp64 pipes idle a third of the time; a third sweep per pass costs arithmetic only.  With the
 // perimeter constant, the perimeter value of every intermediate field is the input's own value at that node, so no `mid` array,
 // no ring and no perimeter-row kernel take part.  A wave loads the 64 columns c0-H .. c0+63-H and owns the 64-2H output columns
-// c0 .. c0+63-2H (H = 4: 56 columns, every stored segment a whole number of 64 B sectors; three sweeps need 3); row chunks overlap
+// c0 .. c0+63-2H (H = 3: 58 columns); row chunks overlap
 // by 3 rows either side.  Same arithmetic as three K2 launches, bit for bit (tests/test_gpu_fused.py, test_gpu_benchsize.py).
 // ------------------------------------------------------------------------------------------
 #ifndef TM_R3_WAVES
 #define TM_R3_WAVES 1
 #endif
 constexpr int R3_U = 3;                 // rows per load group
-constexpr int R3_H = 4;                 // halo lanes per side
+constexpr int R3_H = 3;                 // halo lanes per side (4 would make every stored segment whole 64 B sectors: slower, 39.4 against 38.4 us per sweep at 4096^2, 12.6 against 11.45 at 2048^2)
 constexpr int R3_W = 64 - 2 * R3_H;     // output columns per wave
 template <int DOT, int U, int NT, bool W1, bool INSIDE>
 __device__ __forceinline__ void relax3_strip(const Relax2Block& a, const Relax2Tile& t, double (&acc)[MAX_PARTIALS]) {
