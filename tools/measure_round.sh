@@ -7,19 +7,16 @@ mkdir -p gpurun_out
 {
   echo "# $tag measurements, $(date -u +%Y-%m-%dT%H:%MZ), $(python3 -c 'import torch; print(torch.cuda.get_device_name(0))' 2>/dev/null)"
   echo "## K1 (tools/tfi_probe.py)"; python3 tools/tfi_probe.py 4096 2>/dev/null; python3 tools/tfi_probe.py 2048 2>/dev/null
-  echo "## single-rank relaxation sweeps (two per pass), us per sweep"
-  python3 - <<'PY' 2>/dev/null
-import sys
-sys.path.insert(0, ".")
-from turbomesh_amd import configs
-from turbomesh_amd.smoothing import smooth, solver
-for n in (1024, 2048, 4096):
-    m = configs.single_block(n, n)
-    with smooth.Smoother(m, solver.Option.hip(inner=solver.Inner.relax)) as sm:
-        sm.iterate(20)
-        st = sm.iterate(400)
-    print(f"{n}^2 single block: {st['seconds'] / 400 * 1e6:.1f} us per sweep")
-PY
+  echo "## single-rank relaxation sweeps at settled clocks (tools/dev/steady_time.py): three per pass (fixed perimeter), then two per pass"
+  python3 tools/dev/steady_time.py 1024 1448 2048 2896 4096 2>/dev/null
+  TM_FUSE_3=0 python3 tools/dev/steady_time.py 1024 1448 2048 2896 4096 2>/dev/null
+  echo "## the same from a cold start, consecutive calls of 200 sweeps (tools/dev/ramp_probe.py)"
+  python3 tools/dev/ramp_probe.py 4096 200 12 2>/dev/null
+  TM_FUSE_3=0 python3 tools/dev/ramp_probe.py 4096 200 12 2>/dev/null
+  echo "## shader clock / power while the pass runs (tools/dev/clock_probe.py)"
+  python3 tools/dev/clock_probe.py 3 2>/dev/null | tail -4 | cut -c1-400
+  echo "## STREAM-style copy variants, 256 MiB and 64 MiB per array, alternating direction (tools/ubench/stream.hip)"
+  if [ -x tools/ubench/stream_bin ]; then ./tools/ubench/stream_bin 256 1 | grep -E "MiB|grid  *8192|hipMemcpy"; ./tools/ubench/stream_bin 64 1 | grep -E "MiB|grid  *8192|hipMemcpy"; fi
   echo "## one rank of a strip, transport that moves nothing (tools/split_path_cost.py), signal / wait kernels"
   for n in 4096 2048 1024; do python3 tools/split_path_cost.py $n 2>/dev/null | grep Native; done
   echo "## the same with hipEvent record / wait (TM_PAIR_SYNC=events)"
@@ -29,7 +26,8 @@ PY
   python3 tools/t106_probe.py T106 2>/dev/null | tail -1; python3 tools/t106_probe.py LS89 2>/dev/null | tail -1
   echo "## plain BiCGStab (diagonal), time per inner iteration (tools/bicgstab_iter_probe.py)"
   python3 tools/bicgstab_iter_probe.py 4096 200 2>/dev/null | tail -1; python3 tools/bicgstab_iter_probe.py 1024 500 2>/dev/null | tail -1; python3 tools/bicgstab_iter_probe.py 256 500 2>/dev/null | tail -1
-  echo "## perturbed 4096^2 block to a scaled residual <= 1e-8 (tools/solve_probe.py)"; python3 tools/solve_probe.py 4096 1e-6 1e-10 2>/dev/null
+  echo "## perturbed 4096^2 block to a scaled residual <= 1e-8 (tools/solve_probe.py)"; python3 tools/solve_probe.py 4096 1e-6 1e-6 1e-10 2>/dev/null
+  echo "## the same with one operator application per pass in the multigrid cycle (TM_MG_PAIR=0)"; TM_MG_PAIR=0 python3 tools/solve_probe.py 4096 1e-6 1e-6 1e-10 2>/dev/null
   echo "## host-buffer seam, PCIe inclusive (tools/oneshot_probe.py)"; python3 tools/oneshot_probe.py 2>/dev/null | tail -4
 } > "$out" 2>&1
 cat "$out"

@@ -454,6 +454,11 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         poff2_edge = off2;
         nwg_apply2 = off2 + edge_nf.nwg;
     }
+    // A single process with coupled blocks (BASELINE configs[3] on one GPU: 8 x 2048^2, seven interfaces): the two perimeter-row passes
+    // of a pair are latency-bound (16 us each between two bandwidth-bound launches, 14 % of the pair) -- run them on the chain's queue
+    // beside the interior workgroups like a rank with neighbours does (relax_pairs_pipelined; nothing is exchanged)
+    pipelined_single = fuse_pairs && !(has_hooks && (lp.send_ids.size() > 0 || !lp.ghost_gid.empty())) && edge_nf.nrows > 0 && lp.n_owned >= (1 << 21);
+    if (const char* e = std::getenv("TM_SINGLE_PIPELINED")) pipelined_single = pipelined_single && std::atoi(e) != 0;
     // three sweeps per pass (K2x3): every perimeter row of every owned block `fixed` (nothing for a perimeter-row kernel to do, no
     // neighbour to exchange with) -- a single block with prescribed walls, independent slices
     fuse_triples = fuse_pairs && edge_nf.nrows == 0 && !(has_hooks && (!lp.send_ids.empty() || !lp.ghost_gid.empty()));
@@ -1230,7 +1235,7 @@ void Smoother::relax_sweeps(uint64_t n, tm_stats& st) {
     if (fuse_pairs && n - k >= 2) {
         const uint64_t npairs = (n - k) / 2;
         const bool last_is_pair = (n - k) % 2 == 0;
-        if (has_hooks && (n_send > 0 || n_ghost > 0)) {
+        if ((has_hooks && (n_send > 0 || n_ghost > 0)) || pipelined_single) {
             relax_pairs_pipelined(npairs, last_is_pair);
         } else {
             for (uint64_t q = 0; q < npairs; ++q) relax_pair(q + 1 == npairs && last_is_pair);

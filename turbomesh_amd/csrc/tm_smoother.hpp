@@ -109,6 +109,7 @@ struct Smoother {
     std::vector<int> poff3, rows3;  // ... and for the three-sweep launches (all perimeter rows fixed)
     int nwg_apply3 = 0;
     bool fuse_triples = false;
+    bool pipelined_single = false;   // single process, coupled blocks: perimeter-row passes on the chain's queue beside the interior pass
     // halo exchange
     int32_t* d_send_ids = nullptr;
     double2* d_send_buf = nullptr;
