@@ -1,0 +1,69 @@
+"""Entry points added in round 3 (include/tm_hip.h): tm_smoother_iterate_until_update, tm_stream_probe; the three-sweeps-per-pass path."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from tests.conftest import mesh_flat
+from turbomesh_amd import _capi, configs
+from turbomesh_amd.smoothing import smooth, solver
+
+pytestmark = pytest.mark.gpu
+
+
+def test_iterate_until_update_stops_on_the_picard_update_and_reports_the_cap():
+    # the reference's own per-iteration quantity (smooth.zig:112-137): sqrt((sum dx^2 + sum dy^2) / nodes) of the last outer iteration
+    n = 257
+    mesh = configs.single_block(n, n, perturb=0.25)
+    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab)) as sm:
+        reached, st = sm.iterate_until_update(1e-9, 100)
+        upd = np.sqrt((st["last_dx2"] + st["last_dy2"]) / (n * n))
+        assert reached and upd <= 1e-9 and 2 <= st["outer_iterations"] <= 40, st
+        reached2, st2 = sm.iterate_until_update(1e-30, 2)      # unreachable: stops at the cap and says so
+        assert not reached2 and st2["outer_iterations"] == 2
+    relax = configs.single_block(33, 33, perturb=0.25)
+    with smooth.Smoother(relax, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+        reached, st = sm.iterate_until_update(1e-9, 100000)   # relax mode tests every 32 sweeps
+        assert reached and st["outer_iterations"] % 32 == 0
+        assert np.sqrt((st["last_dx2"] + st["last_dy2"]) / (33 * 33)) <= 1e-9
+    with pytest.raises(_capi.TmError):
+        with smooth.Smoother(configs.single_block(9, 9)) as sm:
+            sm.iterate_until_update(0.0, 3)
+
+
+def test_stream_probe_reports_a_plausible_ceiling():
+    cp, tr = C.c_double(0), C.c_double(0)
+    _capi.check(_capi.lib().tm_stream_probe(64 << 20, 10, C.byref(cp), C.byref(tr)))
+    assert 2000.0 < cp.value < 12000.0 and 2000.0 < tr.value < 12000.0, (cp.value, tr.value)
+    assert _capi.lib().tm_stream_probe(16, 10, C.byref(cp), C.byref(tr)) == _capi.TM_E_ARG
+
+
+@pytest.mark.parametrize("shape", [(7, 7), (8, 61), (64, 59), (70, 131), (131, 300), (40, 1000)])
+def test_three_sweeps_per_pass_equal_single_sweeps(shape, monkeypatch):
+    # K2x3 (blocks whose perimeter rows are all fixed) against one sweep per pass, every split of the sweep count into triples, pairs
+    # and single sweeps, around the 58-column strip seams and the chunk seams; and with omega != 1 (the general update form)
+    unit = None
+    for omega in (0.0, 0.7):
+        out = []
+        for single in (True, False):
+            mesh = configs.single_block(shape[0], shape[1], perturb=0.2)
+            hist = []
+            with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax, single_sweep=single, omega=omega)) as sm:
+                for nsweeps in (3, 4, 5, 6, 1, 2):
+                    st = sm.iterate(nsweeps)
+                    sm.download()
+                    hist.append((mesh_flat(mesh).copy(), st["last_dx2"], st["last_dy2"]))
+            out.append(hist)
+        for (a, ax, ay), (b, bx, by) in zip(*out):
+            assert np.array_equal(a, b), float(np.abs(a - b).max())
+            assert bx == pytest.approx(ax, rel=1e-10, abs=1e-300) and by == pytest.approx(ay, rel=1e-10, abs=1e-300)
+        if omega == 0.0:
+            unit = out[0][-1][0]
+    # the knob: TM_FUSE_3=0 gives pairs, same bits
+    monkeypatch.setenv("TM_FUSE_3", "0")
+    mesh = configs.single_block(shape[0], shape[1], perturb=0.2)
+    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+        for nsweeps in (3, 4, 5, 6, 1, 2):
+            sm.iterate(nsweeps)
+        sm.download()
+    assert np.array_equal(mesh_flat(mesh), unit)
