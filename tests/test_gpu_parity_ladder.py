@@ -144,3 +144,37 @@ def test_1025_both_routes_reach_the_same_fixed_point():
     rms = _rms(res[0], res[1])
     log_parity("ladder_block1025_fixed_point_mg_vs_bicgstab_rms", rms)
     assert rms <= TOL_RMS, rms
+
+
+@pytest.mark.parametrize("name", ["T106", "LS89"])
+def test_o4h_examples_at_four_times_the_nodes(name):
+    # Every row kind of the reference at scale -- interfaces, 3 periodic connections, 12 junction points, sliding inlet / outlet rows,
+    # Roberts boundary-layer clustering, the White control function of the JSON -- on the example meshes with every num_cells entry
+    # doubled (T106: 98 228 nodes, LS89: 147 398; x3 / x4 leave the domain of the reference's tanh clustering formula,
+    # clustering.zig:56-95).  Two Picard iterates, default options, against the sparse-LU oracle (tools/dev/o4h_refined_probe.py
+    # also runs the multigrid route: 5e-13 / 9e-14).
+    import json
+    import os
+
+    from tests.test_o4h import GOLD
+    from turbomesh_amd.input import Input
+    from turbomesh_amd.smoothing import wall_control_function as wcf
+
+    j = json.load(open(os.path.join(GOLD, "examples", name, name + ".json")))
+    nc = j["template"]["O4H"]["num_cells"]
+    for k in nc:
+        nc[k] *= 2
+    inp = Input.parse(json.dumps(j))
+    build = lambda: inp.template.run(inp.geometry(GOLD), tfi=None)
+    mesh = build()
+    w = inp.wall_control_function.white
+    ref = _flat(oracle.picard_exact(OracleMesh(mesh), 2, control=("white", w.ds_target, w.theta_target), keep_iterates=True)[1])
+    worst = 0.0
+    with smooth.Smoother(mesh, solver.Option.hip(), wcf.Algorithm(wcf.White(w.ds_target, w.theta_target))) as sm:
+        for k in range(2):
+            st = sm.iterate(1)
+            sm.download()
+            assert st["not_converged"] == 0, st
+            worst = max(worst, _rms(mesh_flat(mesh), ref[k]))
+    log_parity(f"ladder_{name}_x2_white_bicgstab_rms", worst)
+    assert worst <= TOL_RMS, worst
