@@ -67,3 +67,27 @@ def test_three_sweeps_per_pass_equal_single_sweeps(shape, monkeypatch):
             sm.iterate(nsweeps)
         sm.download()
     assert np.array_equal(mesh_flat(mesh), unit)
+
+
+def test_relax_sweep_with_the_white_control_function_matches_the_mirror():
+    # MODE_RELAX with (P, Q) and omega = 1 takes the Jacobi form x_new = q / (2 D) with the control-function terms inside q
+    # (winslow_row); the oracle's mirror makes the same step: interior rows of both blocks of the White plate, bit for bit
+    from oracle import oracle
+    from tests.meshes import TOPOLOGIES
+    from turbomesh_amd.smoothing import wall_control_function as wcf
+
+    mesh = TOPOLOGIES["plate_le"]()
+    x0 = [b.points.data.copy() for b in mesh.blocks]
+    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax, single_sweep=True), wcf.Algorithm(wcf.White(0.02))) as sm:
+        pq = sm.control_function()
+        sm.iterate(1)
+        sm.download()
+    assert np.abs(pq).max() > 0
+    off = 0
+    for b, x in zip(mesh.blocks, x0):
+        ni, nj = x.shape[:2]
+        pqb = np.ascontiguousarray(pq[off:off + ni * nj].reshape(ni, nj, 2))
+        off += ni * nj
+        ref = oracle.mirror_apply_block(oracle.MIRROR_RELAX, x, x, pq=pqb, omega=1.0, out=x.copy())
+        assert np.array_equal(b.points.data[1:-1, 1:-1], ref[1:-1, 1:-1]), float(np.abs(b.points.data[1:-1, 1:-1] - ref[1:-1, 1:-1]).max())
+        assert not np.array_equal(b.points.data[1:-1, 1:-1], x[1:-1, 1:-1])
