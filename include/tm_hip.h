@@ -122,11 +122,16 @@ enum {
 enum {
     TM_OPT_SINGLE_SWEEP = 1, /* TM_INNER_RELAX: one kernel pass per sweep.  Default (bit clear): sweeps are taken two per pass
                                 where the blocks allow it (same arithmetic, bit-identical coordinates, half the HBM traffic) */
-    TM_OPT_EAGER_SCALARS = 2 /* Krylov modes: the textbook launch sequence of BiCGStab.zig:279-370 -- one kernel per vector update, one
+    TM_OPT_EAGER_SCALARS = 2, /* Krylov modes: the textbook launch sequence of BiCGStab.zig:279-370 -- one kernel per vector update, one
                                 scalar-update launch per reduction.  Default (bit clear) on single-process handles: the vector updates
                                 are formed inside the two operator applications (two kernels per iteration; rho from r_hat.s -
                                 omega r_hat.t, equal in exact arithmetic) and, on small meshes, the scalar steps travel with the
                                 kernels that consume them.  Same method, iterates equal to rounding */
+    TM_OPT_RTOL_INITIAL = 4  /* Krylov modes: `rtol` is relative to the INITIAL residual of each inner solve (inexact Picard: stop at
+                                ||D^-1(b-Ax)|| <= max(atol, rtol ||D^-1(b-A x0)||), rtol = 0 -> 1e-2) instead of ||D^-1 b||.  Every solve then
+                                does work in proportion to what is left -- same fixed point, several times fewer inner iterations on the way
+                                (tools/converge_probe.py); the Picard ITERATES are no longer the exact-solve ones, so parity per iterate is
+                                a statement about the default mode only */
 };
 typedef struct tm_solver_opt {
     int32_t tag;             /* TM_SOLVER_* */

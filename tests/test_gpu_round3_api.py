@@ -91,3 +91,21 @@ def test_relax_sweep_with_the_white_control_function_matches_the_mirror():
         ref = oracle.mirror_apply_block(oracle.MIRROR_RELAX, x, x, pq=pqb, omega=1.0, out=x.copy())
         assert np.array_equal(b.points.data[1:-1, 1:-1], ref[1:-1, 1:-1]), float(np.abs(b.points.data[1:-1, 1:-1] - ref[1:-1, 1:-1]).max())
         assert not np.array_equal(b.points.data[1:-1, 1:-1], x[1:-1, 1:-1])
+
+
+def test_inexact_picard_reaches_the_same_fixed_point_with_fewer_inner_iterations():
+    # TM_OPT_RTOL_INITIAL: the inner tolerance relative to each solve's INITIAL residual.  Every solve iterates (a tolerance relative
+    # to ||D^-1 b|| that the warm start already meets would return at once and fake a zero update), the fixed point is the same,
+    # the inner iterations on the way are several times fewer.
+    n = 513
+    res = []
+    for kw in (dict(), dict(rtol=1e-2, rtol_initial=True)):
+        mesh = configs.single_block(n, n, perturb=0.25)
+        with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab, check_every=1, **kw)) as sm:
+            reached, st = sm.iterate_until_update(1e-11, 200)
+            sm.download()
+        assert reached and st["not_converged"] == 0, st
+        res.append((mesh.blocks[0].points.data.copy(), st["inner_iterations"], st["outer_iterations"]))
+        print(f"[inexact picard] {kw or 'default'}: outer {st['outer_iterations']}, inner {st['inner_iterations']}, {st['seconds'] * 1e3:.1f} ms")
+    assert float(np.sqrt(np.mean((res[0][0] - res[1][0]) ** 2))) <= 1e-9
+    assert res[1][1] * 2 <= res[0][1] and res[1][1] >= res[1][2]          # at least one inner iteration per outer one

@@ -2249,10 +2249,16 @@ int vec_nwg(int64_t n) {
 __device__ __forceinline__ void scalar_update_body(KrylovScalars* S, const double* red, int step, double rtol, double atol, int c) {
     const double tiny = 1e-290;
     if (step == STEP_TOL) {
+        if (rtol < 0.0) {   // TM_OPT_RTOL_INITIAL: the tolerance is relative to the solve's INITIAL residual, known at STEP_INIT -- parked until then
+            S->tol2[c] = -(rtol * rtol);
+            S->rr[c] = atol * atol;
+            return;
+        }
         const double tol = fmax(atol, rtol * sqrt(red[c]));
         S->tol2[c] = tol * tol;
         return;
     }
+    if ((step == STEP_INIT || step == STEP_INIT2) && S->tol2[c] < 0.0) S->tol2[c] = fmax(S->rr[c], -S->tol2[c] * red[c]);   // (a restart keeps it)
     if (step == STEP_INIT) {   // red[0..1] = ||r0||^2 ; r_hat = r0 so rho = ||r0||^2
         const double rr = red[c];
         S->rr[c] = rr;

@@ -157,7 +157,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
 
     topo = topology_from_desc(mesh);
     dof_global = topo.dof;
-    if (!(opt.rtol > 0)) opt.rtol = default_rtol(static_cast<double>(dof_global));
+    if (!(opt.rtol > 0)) opt.rtol = (opt.flags & TM_OPT_RTOL_INITIAL) ? 1e-2 : default_rtol(static_cast<double>(dof_global));
     if (opt.max_inner == 0) opt.max_inner = default_max_inner(static_cast<double>(dof_global));
     try {
         all_rows = build_rows(topo);
@@ -904,7 +904,7 @@ int Smoother::picard_bicgstab(tm_stats& st) {
     HIPCHK(hipMemcpyAsync(U, X, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));
     // tolerance from ||D^-1 b||
     HIPCHK(launch_edge_rhs(edge, X, PQ, nullptr, 1, partials, stream));
-    reduce_update(edge.nwg, STEP_TOL, opt.rtol, opt.atol);
+    reduce_update(edge.nwg, STEP_TOL, (opt.flags & TM_OPT_RTOL_INITIAL) ? -opt.rtol : opt.rtol, opt.atol);
 
     int restarts = 0;
     uint64_t it_total = 0;

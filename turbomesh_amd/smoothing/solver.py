@@ -48,6 +48,7 @@ class Option:
     check_every: int = 0       # 0 -> 8
     omega: float = 0.0         # 0 -> 1.0
     single_sweep: bool = False # relax: one kernel pass per sweep (default: two sweeps per pass where possible)
+    rtol_initial: bool = False   # Krylov modes: rtol relative to the initial residual of each inner solve (inexact Picard; rtol 0 -> 1e-2)
     eager_scalars: bool = False  # Krylov modes: the textbook launch sequence (a kernel per vector update, a launch per scalar step); default: two fused kernels per iteration
 
     @classmethod
@@ -56,7 +57,7 @@ class Option:
 
     def c_struct(self):
         return _capi.tm_solver_opt(int(self.tag), int(self.inner), self.rtol, self.atol, self.max_inner, self.check_every,
-                                   (1 if self.single_sweep else 0) | (2 if self.eager_scalars else 0), self.omega)
+                                   (1 if self.single_sweep else 0) | (2 if self.eager_scalars else 0) | (4 if self.rtol_initial else 0), self.omega)
 
 
 class Solver:
