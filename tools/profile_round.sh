@@ -18,6 +18,8 @@ prof mg_solve4096 python3 "$root/tools/solve_probe.py" 4096 1e-6
 prof config4_8x2048 python3 "$root/bench.py" --config 4 --no-cpu-baseline --steps 100
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d "$out/pmc_fetch" -o p -- python3 "$root/tools/prof_sweep.py" 4096 20 relax > /dev/null 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d "$out/pmc_write" -o p -- python3 "$root/tools/prof_sweep.py" 4096 20 relax > /dev/null 2>&1
+rocprofv3 --kernel-trace --pmc SQ_INSTS_VALU SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_ANY SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_WAVES --output-format csv -d "$out/pmc_sq" -o p -- python3 "$root/tools/prof_sweep.py" 4096 21 relax > /dev/null 2>&1
+cp "$out"/pmc_sq/p_counter_collection.csv "$out/${tag}_pmc_sq_k2x3_counter_collection.csv" 2>/dev/null
 cp "$out"/pmc_fetch/p_counter_collection.csv "$out/${tag}_pmc_fetch_counter_collection.csv" 2>/dev/null
 cp "$out"/pmc_write/p_counter_collection.csv "$out/${tag}_pmc_write_counter_collection.csv" 2>/dev/null
 cd "$root"
