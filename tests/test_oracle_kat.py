@@ -215,3 +215,30 @@ def test_threaded_relax_sweeps_equal_single_thread():
     oracle.time_relax_sweeps(a, 5)
     oracle.time_relax_sweeps_mt(b, 5, 6)
     assert np.array_equal(a, b) and not np.array_equal(a, xy)
+
+
+def test_mirror_jacobi_form_against_the_reference_order_csr():
+    # The device's relaxation sweep with omega = 1 takes the textbook Jacobi form x_new = (b - sum_{k != i} a_ik x_k) / a_ii evaluated
+    # from factored metric terms (oracle/orc_mirror.cpp MIRROR_RELAX, tm_kernels.hip winslow_row).  Tie it to the reference's own
+    # arithmetic: the same step from the faithfully assembled CSR (coefficients smooth.zig:171-216, rows smooth.zig:923-992), term by
+    # term in CSR order -- equal to rounding (a few eps of the neighbourhood's magnitude), on a rough field and on a stretched one.
+    import scipy.sparse as sp
+
+    for ni, nj, perturb in ((23, 31, 0.25), (9, 140, 0.1)):
+        mesh = configs.single_block(ni, nj, tfi=oracle_tfi, perturb=perturb)
+        om = OracleMesh(mesh)
+        s = oracle.System(om)
+        s.fill(0)
+        A = s.csr()
+        x = om.blocks[0].reshape(-1, 2).copy()
+        d = A.diagonal()
+        off = A - sp.diags(d)
+        b = np.stack([s.rhs_x, s.rhs_y], axis=1)
+        jac = (b - np.stack([off @ x[:, 0], off @ x[:, 1]], axis=1)) / d[:, None]
+        mir = oracle.mirror_apply_block(oracle.MIRROR_RELAX, om.blocks[0], om.blocks[0], omega=1.0, out=om.blocks[0].copy()).reshape(-1, 2)
+        interior = np.zeros((ni, nj), dtype=bool)
+        interior[1:-1, 1:-1] = True
+        m = interior.reshape(-1)
+        scale = np.abs(x).max()
+        assert np.abs(mir[m] - jac[m]).max() <= 32 * np.finfo(float).eps * scale, np.abs(mir[m] - jac[m]).max()
+        assert np.abs(mir[m] - x[m]).max() > 1e-6           # the step does move the nodes
