@@ -9,7 +9,9 @@ in TM_INNER_RELAX mode, run through the C-ABI handle with the coordinates reside
 
   --config 2 (default)  N = 1: BASELINE configs[1] -- single synthetic 4096 x 4096 block, TFI
                         seeded on the GPU.  N > 1: weak scaling -- a strip of N such blocks stacked in i, one per GPU,
-                        coupled by interface rows exchanged point-to-point (RCCL over xGMI) between sweeps.
+                        coupled by interface rows exchanged point-to-point (RCCL over xGMI) between sweeps.  (A lone block
+                        with fixed walls runs three sweeps per kernel pass, coupled blocks two: the N = 1 value is not the
+                        per-GPU ceiling of the N > 1 runs -- 39.5 against 53-57 us per sweep -- see DESIGN.md section 6.)
   --config 4            BASELINE configs[3], STRONG scaling: 8 coupled blocks of 2048^2, 8/N blocks per GPU.
   --config 5            BASELINE configs[4]: independent 2048^2 slices, 8 per GPU ("replicas only": no communication).
 
@@ -254,7 +256,7 @@ def main():
     ap.add_argument("--unroll", type=int, default=0, help="K2 row unroll (tuning)")
     ap.add_argument("--pipe", type=int, default=-1, help="K2 software pipelining 0/1 (tuning)")
     ap.add_argument("--nt", type=int, default=-1, help="K2 non-temporal stores 0/1 (tuning)")
-    ap.add_argument("--single-sweep", action="store_true", help="one kernel pass per sweep (K2) instead of two sweeps per pass (K2x2)")
+    ap.add_argument("--single-sweep", action="store_true", help="one kernel pass per sweep (K2) instead of three (K2x3, fixed walls) or two (K2x2, coupled blocks) sweeps per pass")
     ap.add_argument("--fuse-rows", type=int, default=0, help="K2x2 rows per chunk (tuning)")
     ap.add_argument("--settle-ms", type=float, default=250.0,
                     help="untimed sweeps of the same workload before the W warm-up steps, so that the timed region runs at settled clocks (0 = off)")
@@ -480,7 +482,7 @@ def main():
 
     if rank == 0:
         k2_avg_s = (k2_ms / 1e3) / max(1, k2_timed)
-        sweeps_per_launch = st["operator_sweeps"] / max(1, k2_launches)   # one launch takes this rank's blocks through 1 (K2) or 2 (K2x2) sweeps
+        sweeps_per_launch = st["operator_sweeps"] / max(1, k2_launches)   # one launch takes this rank's blocks through 1 (K2), 2 (K2x2) or 3 (K2x3) sweeps
         whole_job_timing = coupled or args.config == 4
         if whole_job_timing:
             # coupled blocks: the interior part of a pass waits in its queue for the border part of the previous one, so an event pair
@@ -490,7 +492,7 @@ def main():
         spl = int(round(sweeps_per_launch))
         kname = {1: "k_apply", 2: "k_relax2", 3: "k_relax3"}.get(spl, "k_relax2")
         # what ONE launch of the dominant kernel has to move: every owned node read once and written once, however many
-        # sweeps it performs on the way (K2x2: two).  achieved / peak is therefore a true bandwidth fraction, <= 1.
+        # sweeps it performs on the way (K2x2: two, K2x3: three).  achieved / peak is therefore a true bandwidth fraction, <= 1.
         bytes_per_launch = BYTES_PER_NODE * nodes_rank
         achieved = bytes_per_launch / k2_avg_s / 1e9
         traffic, traffic_src = None, None

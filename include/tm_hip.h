@@ -120,8 +120,9 @@ enum {
 };
 /* tm_solver_opt.flags */
 enum {
-    TM_OPT_SINGLE_SWEEP = 1, /* TM_INNER_RELAX: one kernel pass per sweep.  Default (bit clear): sweeps are taken two per pass
-                                where the blocks allow it (same arithmetic, bit-identical coordinates, half the HBM traffic) */
+    TM_OPT_SINGLE_SWEEP = 1, /* TM_INNER_RELAX: one kernel pass per sweep.  Default (bit clear): sweeps are taken three per pass
+                                on blocks whose perimeter rows are all `fixed`, two per pass on coupled blocks (same arithmetic,
+                                bit-identical coordinates, a third / half of the HBM traffic) */
     TM_OPT_EAGER_SCALARS = 2, /* Krylov modes: the textbook launch sequence of BiCGStab.zig:279-370 -- one kernel per vector update, one
                                 scalar-update launch per reduction.  Default (bit clear) on single-process handles: the vector updates
                                 are formed inside the two operator applications (two kernels per iteration; rho from r_hat.s -
@@ -306,7 +307,7 @@ int tm_export_soa(const double* xy /* ni*nj*2 */, uint64_t ni, uint64_t nj, doub
 int tm_smoother_export_soa(tm_smoother* s, uint64_t block, double* x, double* y, double* p, double* q);
 
 /* Measurement support (bench.py roofline): with every = k > 0, every k-th launch of the dominant kernel (K2
- * `winslow_apply` / K2x2) is bracketed by a pair of HIP events recorded on the handle's stream (0 = off); read returns
+ * `winslow_apply` / K2x2 / K2x3) is bracketed by a pair of HIP events recorded on the handle's stream (0 = off); read returns
  * the summed elapsed milliseconds of the bracketed launches, how many were bracketed and how many ran since the last
  * read (and resets all three). */
 int tm_smoother_profile(tm_smoother* s, int every);

@@ -47,7 +47,7 @@ class Option:
     max_inner: int = 0         # 0 -> max(10000, 12 sqrt(nodes)) (the reference: 1000, BiCGStab.zig:19, with its looser stop test)
     check_every: int = 0       # 0 -> 8
     omega: float = 0.0         # 0 -> 1.0
-    single_sweep: bool = False # relax: one kernel pass per sweep (default: two sweeps per pass where possible)
+    single_sweep: bool = False # relax: one kernel pass per sweep (default: three per pass with fixed walls, two on coupled blocks)
     rtol_initial: bool = False   # Krylov modes: rtol relative to the initial residual of each inner solve (inexact Picard; rtol 0 -> 1e-2)
     eager_scalars: bool = False  # Krylov modes: the textbook launch sequence (a kernel per vector update, a launch per scalar step); default: two fused kernels per iteration
 
