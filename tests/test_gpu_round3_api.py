@@ -109,3 +109,41 @@ def test_inexact_picard_reaches_the_same_fixed_point_with_fewer_inner_iterations
         print(f"[inexact picard] {kw or 'default'}: outer {st['outer_iterations']}, inner {st['inner_iterations']}, {st['seconds'] * 1e3:.1f} ms")
     assert float(np.sqrt(np.mean((res[0][0] - res[1][0]) ** 2))) <= 1e-9
     assert res[1][1] * 2 <= res[0][1] and res[1][1] >= res[1][2]          # at least one inner iteration per outer one
+
+
+@pytest.mark.parametrize("kind", ["strip3", "strip2_reversed", "two_by_two"])
+def test_three_sweeps_per_pass_on_coupled_blocks(kind, monkeypatch):
+    # Coupled blocks of a single process: K2x3 with a frozen perimeter stores everything but the nodes within two of a side whose
+    # perimeter rows move; the perimeter-row kernel evaluates the perimeter and that zone level by level (Smoother::
+    # relax_triples_coupled).  Bit-identical to single sweeps: row interfaces, reversed ranges, column interfaces and a junction
+    # point (two_by_two), every split of the sweep count into triples, pairs and single sweeps.
+    build = {"strip3": lambda: configs.strip(3, 900, 800), "strip2_reversed": lambda: configs.strip(2, 1100, 1000, reverse_odd=True),
+             "two_by_two": lambda: configs.two_by_two(760, 720)}[kind]
+    hist = {}
+    for mode in ("triples", "single"):
+        mesh = build()
+        rng = np.random.default_rng(3)
+        for b in mesh.blocks:   # roughen the interiors (the interfaces stay matched)
+            d = b.points.data
+            d[1:-1, 1:-1] += 0.2 / d.shape[0] * (rng.random(d[1:-1, 1:-1].shape) - 0.5)
+        out = []
+        with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax, single_sweep=(mode == "single"))) as sm:
+            for nsweeps in (3, 7, 5, 6):
+                st = sm.iterate(nsweeps)
+                sm.download()
+                out.append((mesh_flat(mesh).copy(), st["last_dx2"], st["last_dy2"]))
+        hist[mode] = out
+    for (a, ax, ay), (b, bx, by) in zip(hist["triples"], hist["single"]):
+        assert np.isfinite(a).all()
+        assert np.array_equal(a, b), (kind, float(np.abs(a - b).max()), int(np.any(a != b, axis=1).sum()))
+        assert ax == pytest.approx(bx, rel=1e-10, abs=1e-300) and ay == pytest.approx(by, rel=1e-10, abs=1e-300)
+    monkeypatch.setenv("TM_TRIPLES_COUPLED", "0")   # the knob: pairs, same bits
+    mesh = build()
+    rng = np.random.default_rng(3)
+    for b in mesh.blocks:
+        d = b.points.data
+        d[1:-1, 1:-1] += 0.2 / d.shape[0] * (rng.random(d[1:-1, 1:-1].shape) - 0.5)
+    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+        sm.iterate(3)
+        sm.download()
+    assert np.array_equal(mesh_flat(mesh), hist["single"][0][0])

@@ -138,7 +138,7 @@ struct EdgeRun {
     int32_t col0[9], col_stride[9];  // its columns, ascending GLOBAL id order (the reference's CSR order)
     int32_t met0[4], met_stride[4];  // smoothed rows: im1_j, ip1_j, i_jm1, i_jp1
     int8_t kind, ncols, self;        // BlockBoundaryPointKind (5 = interior node of a remote block), #columns, diagonal position
-    uint8_t flags;                   // bit0 periodic, bit1 swap (Q,P), bit2 / bit3: rhs_x / rhs_y = the row's current value (ghost copies)
+    uint8_t flags;                   // bit0 periodic, bit1 swap (Q,P), bit2 / bit3: rhs_x / rhs_y = the row's current value (ghost copies), bit4: kind 5 row of an OWNED node (its displacement enters DOT_DELTA)
     int8_t slot[9];                  // smoothed rows: stencil slot per column
     int8_t _pad[3];
     double cx[9], cy[9];             // static x / y system coefficients

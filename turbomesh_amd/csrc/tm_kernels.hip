@@ -956,7 +956,12 @@ __device__ __forceinline__ void relax3_strip(const Relax2Block& a, const Relax2T
     const bool perim_col = !INSIDE && ((t.c <= 0) || (t.c >= nj - 1));
     const int nrows = t.i1 - t.i0;
     const __amdgpu_buffer_rsrc_t out_rsrc = __builtin_amdgcn_make_buffer_rsrc(a.out + static_cast<size_t>(t.i0) * nj, 0, nrows * nj * 16, 0x00020000);
-    const unsigned lane_off = t.out_lane ? static_cast<unsigned>(cc) * 16u : OOB_VOFFSET;
+    // Coupled blocks (Relax2Block::dyn != 0, Smoother::relax_triples_coupled): the pass treats every perimeter value as frozen, which is
+    // wrong along a side whose perimeter rows move -- but three sweeps carry that error only two nodes deep, so the pass simply does
+    // not store the nodes within two of such a side; the perimeter-row kernel evaluates them (and the perimeter) level by level.
+    const bool skip_col = !INSIDE && (((a.dyn & 4) && t.c <= 2) || ((a.dyn & 8) && t.c >= nj - 3));
+    const bool live_lane = t.out_lane && !skip_col;
+    const unsigned lane_off = live_lane ? static_cast<unsigned>(cc) * 16u : OOB_VOFFSET;
     const double2 zero = make_double2(0.0, 0.0);
 
     Row3 A[3], S1[3], S2[3];
@@ -991,12 +996,12 @@ __device__ __forceinline__ void relax3_strip(const Relax2Block& a, const Relax2T
             double2 d3 = zero;
             const double2 o = relax_row<W1>(S2[A0], S2[A1], S2[A2], a.omega, d3);   // row r-3
             const int i = r - 3;
-            const bool row_live = (i >= t.i0) && (i < t.i1);   // wave-uniform
+            const bool row_live = (i >= t.i0) && (i < t.i1) && (INSIDE || !(((a.dyn & 1) && i <= 2) || ((a.dyn & 2) && i >= ni - 3)));   // wave-uniform
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, o), out_rsrc,
                                                    static_cast<int>(row_live ? lane_off + static_cast<unsigned>((i - t.i0) * nj * 16) : OOB_VOFFSET), 0,
                                                    (NT & 1) ? 2 : 0);
             if (DOT == DOT_DELTA) {
-                if (!(t.out_lane && row_live)) d3 = zero;   // masked lanes hold garbage (possibly non-finite): select, never multiply
+                if (!(live_lane && row_live)) d3 = zero;   // masked lanes hold garbage (possibly non-finite): select, never multiply
                 accumulate<DOT_DELTA>(acc, S2[A1].c, o, d3);
             }
         }
@@ -1627,6 +1632,7 @@ __device__ __forceinline__ void edge_row_eval(const EdgeRun& R, const double* __
         const double2 c_e = sub2(cr, cl);
         double2 delta;
         result = winslow_row<MODE_RELAX, false>(mc, sub2(mr, ml), cc, c_e, add2(cr, cl), pc, sub2(pr, pl), sub2(pc, mc), c_e, 0.0, 0.0, omega, delta);
+        if (DOT == DOT_DELTA && (R.flags & 16)) accumulate<DOT_DELTA>(acc, cc, result, delta);   // an OWN interior node (coupled triples): its displacement counts
         return;
     }
     if (kind == 1 /* smoothed */) {

@@ -233,6 +233,14 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     for (int64_t b = 0; b < topo.nblocks(); ++b)
         if (has_hooks || owner[b] == lp.rank) fuse_pairs = fuse_pairs && relax2_supported(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
     if (fuse_pairs) M = vec();
+    {   // coupled triples: a single process (no neighbouring rank), large blocks, some perimeter row that moves
+        bool any_nf = false;
+        for (const PlanRow& pr : lp.rows) any_nf = any_nf || pr.kind != KIND_FIXED;
+        triples_coupled = fuse_pairs && any_nf && lp.ghost_gid.empty() && lp.send_ids.empty() && lp.n_owned >= (1 << 21);
+        for (int64_t b : lp.owned_blocks) triples_coupled = triples_coupled && topo.ni[b] >= 16 && topo.nj[b] >= 16 && relax3_supported(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
+        if (const char* e = std::getenv("TM_TRIPLES_COUPLED")) triples_coupled = triples_coupled && std::atoi(e) != 0;
+        if (triples_coupled) M2 = vec();
+    }
     {   // K2x2's result stores (launch_relax2_block): plain while the rank's field is a good fraction of the 256 MB Infinity Cache but not
         // more than it holds beside the field being read -- measured crossovers: 1024^2 (16 MiB) streaming, 1448^2 .. 2896^2 plain, 4096^2 streaming
         const double mib = 16.0 * static_cast<double>(lp.n_owned) / (1024.0 * 1024.0);
@@ -287,7 +295,11 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
             int64_t b = topo.nblocks() - 1;
             while (pr.gid < topo.start[b]) --b;
             const int64_t flat = pr.gid - topo.start[b], bi = flat / topo.nj[b], bj = flat % topo.nj[b];
-            const bool on_row = bi <= 1 || bi >= topo.ni[b] - 2;
+            bool on_row = bi <= 1 || bi >= topo.ni[b] - 2;
+            if (pr.kind == KIND_INTERIOR) {   // zone rows of the coupled triples: runs along the nearer pair of sides
+                on_row = std::min(bi, topo.ni[b] - 1 - bi) <= std::min(bj, topo.nj[b] - 1 - bj);
+                if (h.row < lp.n_owned) h.flags |= 16;
+            }
             h.line = (b << 34) | (static_cast<int64_t>(on_row ? 0 : 1) << 33) | (on_row ? bi : bj);
         }
         auto same_static = [&](size_t x, size_t y) {
@@ -413,6 +425,46 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
             for (const PlanRow& g : lp.ghost_rows) sel.push_back(&g);
             build_table(sel, edge_nf_g, d_rhs_nf_g, order_nf_g);
         }
+        if (triples_coupled) {
+            // level l (1..3) evaluates the moving perimeter rows and, as KIND_INTERIOR rows (K2's own arithmetic on the gathered 3 x 3
+            // neighbourhood), the interior nodes within 5 - l of a side whose perimeter rows move (Chebyshev distance: the 9-point
+            // stencil's dependency cone); what level l reads at level l - 1 lies within 6 - l of such a side or on the perimeter
+            for (int lev = 0; lev < 3; ++lev) {
+                const int64_t depth = 4 - lev;
+                zone_rows[lev].clear();
+                for (size_t kb = 0; kb < lp.owned_blocks.size(); ++kb) {
+                    const int64_t b = lp.owned_blocks[kb], bi_n = topo.ni[b], bj_n = topo.nj[b];
+                    const int dyn = dyn_mask[kb];
+                    if (!dyn) continue;
+                    auto add = [&](int64_t i, int64_t j) {
+                        PlanRow r{};
+                        r.gid = topo.start[b] + i * bj_n + j;
+                        r.kind = KIND_INTERIOR;
+                        r.ncols = 9;
+                        r.self = 4;
+                        int q = 0;
+                        for (int64_t di = -1; di <= 1; ++di)
+                            for (int64_t dj = -1; dj <= 1; ++dj) r.col[q++] = r.gid + di * bj_n + dj;
+                        zone_rows[lev].push_back(r);
+                    };
+                    for (int64_t i = 1; i <= bi_n - 2; ++i) {   // ascending gid
+                        const bool row_in = ((dyn & 1) && i <= depth) || ((dyn & 2) && i >= bi_n - 1 - depth);
+                        if (row_in) {
+                            for (int64_t j = 1; j <= bj_n - 2; ++j) add(i, j);
+                            continue;
+                        }
+                        if (dyn & 4)
+                            for (int64_t j = 1; j <= depth; ++j) add(i, j);
+                        if (dyn & 8)
+                            for (int64_t j = bj_n - 1 - depth; j <= bj_n - 2; ++j) add(i, j);
+                    }
+                }
+                std::vector<const PlanRow*> sl;
+                for (size_t k : nf_rows) sl.push_back(&lp.rows[k]);
+                for (const PlanRow& z : zone_rows[lev]) sl.push_back(&z);
+                build_table(sl, edge_L[lev], d_rhs_L[lev], order_L[lev]);
+            }
+        }
     }
 
     // ---- reductions
@@ -476,8 +528,21 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         }
         nwg_apply3 = off3;
     }
+    if (triples_coupled) {   // the same K2x3 grid, plus the level-3 perimeter-row pass behind it in the partial sums
+        poff3.clear();
+        rows3.clear();
+        int off3 = 0;
+        for (int64_t b : lp.owned_blocks) {
+            const int bi = static_cast<int>(topo.ni[b]), bj = static_cast<int>(topo.nj[b]);
+            poff3.push_back(off3);
+            rows3.push_back(relax3_rows_per_chunk(bi, bj));
+            off3 += relax3_block_nwg(bi, bj, rows3.back());
+        }
+        nwg_apply3 = off3;
+    }
     nwg_vec = vec_nwg(n_owned);
-    const uint64_t npart = static_cast<uint64_t>(std::max(std::max(std::max(nwg_apply, nwg_apply2), fuse_triples ? nwg_apply3 : 0), nwg_vec)) * MAX_PARTIALS;
+    const int nwg3_all = fuse_triples ? nwg_apply3 : (triples_coupled ? nwg_apply3 + edge_L[2].nwg : 0);
+    const uint64_t npart = static_cast<uint64_t>(std::max(std::max(std::max(nwg_apply, nwg_apply2), nwg3_all), nwg_vec)) * MAX_PARTIALS;
     // Krylov modes on a small single-process mesh: the scalar steps travel with the kernels that consume their result (LazyScalars,
     // tm_kernels.h) -- three partial-sum buffers in rotation, two scalar blocks
     lazy = !has_hooks && opt.inner != TM_INNER_RELAX && std::max(nwg_apply, nwg_vec) <= 512 && !(opt.flags & TM_OPT_EAGER_SCALARS);
@@ -568,13 +633,16 @@ void Smoother::upload(const tm_mesh_desc* mesh) {
         }
         HIPCHK(hipMemcpyAsync(dev, staged.data() + base, sizeof(double) * 2 * order.size(), hipMemcpyHostToDevice, stream));
     };
-    staged.reserve(2 * (order_all.size() + order_nf.size() + order_nf_g.size()));   // no reallocation while copies are in flight
+    staged.reserve(2 * (order_all.size() + order_nf.size() + order_nf_g.size() + order_L[0].size() + order_L[1].size() + order_L[2].size()));   // no reallocation while copies are in flight
     put(d_rhs, order_all, [&](int32_t k) { return &h_rhs[2 * static_cast<size_t>(k)]; });
     put(d_rhs_nf, order_nf, [&](int32_t k) { return &h_rhs[2 * nf_rows[k]]; });
     // own rows as above, then the ghost rows' static right-hand sides (coordinate parts come from the row's value)
     put(d_rhs_nf_g, order_nf_g, [&](int32_t k) {
         return static_cast<size_t>(k) < nf_rows.size() ? &h_rhs[2 * nf_rows[k]] : lp.ghost_rows[static_cast<size_t>(k) - nf_rows.size()].rhs;
     });
+    static const double zero_rhs[2] = {0.0, 0.0};   // interior rows have b = 0
+    for (int lev = 0; lev < 3; ++lev)
+        put(d_rhs_L[lev], order_L[lev], [&](int32_t k) { return static_cast<size_t>(k) < nf_rows.size() ? &h_rhs[2 * nf_rows[k]] : zero_rhs; });
     if (opt.inner == TM_INNER_RELAX) prefill_fixed();
     sync();   // host staging buffers may go away after return
 }
@@ -588,6 +656,7 @@ void Smoother::prefill_fixed() {
         const int bi = static_cast<int>(topo.ni[b]), bj = static_cast<int>(topo.nj[b]);
         HIPCHK(launch_copy_perimeter(X + ls, U + ls, bi, bj, stream));
         if (M) HIPCHK(launch_copy_perimeter(X + ls, M + ls, bi, bj, stream));
+        if (M2) HIPCHK(launch_copy_perimeter(X + ls, M2 + ls, bi, bj, stream));
     }
 }
 
@@ -1086,6 +1155,52 @@ void Smoother::relax_triple(bool want_partials) {
     std::swap(X, U);
 }
 
+// Three sweeps per pass on COUPLED blocks of a single process.  K2x3 runs on the whole of every block with the perimeter frozen at
+// X^k; three sweeps carry the error of that only two nodes deep along a side whose perimeter rows move, and the pass does not store
+// those nodes (Relax2Block::dyn).  Beside it, on the chain's queue, the perimeter-row kernel evaluates level by level what the
+// pass cannot: level 1 = the moving perimeter rows of X^(k+1) and the interior nodes within 4 of such a side (from X^k, into M),
+// level 2 = perimeter of X^(k+2) and the nodes within 3 (from M into M2), level 3 = perimeter of X^(k+3) and the nodes within 2
+// (from M2 into the output).  Interior nodes are evaluated as KIND_INTERIOR rows -- K2's own arithmetic, the same bits -- so the
+// result equals three single sweeps bit for bit; the zone is 0.2 % of a 2048^2 block.  One join of the two queues per triple.
+void Smoother::relax_triples_coupled(uint64_t ntriples, bool want_partials_last) {
+    if (!side) {
+        int least = 0, greatest = 0;
+        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+        HIPCHK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest));
+        HIPCHK(hipEventCreateWithFlags(&ev_to_side, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_to_main, hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_inside[0], hipEventDisableTiming));
+        HIPCHK(hipEventCreateWithFlags(&ev_inside[1], hipEventDisableTiming));
+    }
+    std::vector<Relax2Block> blocks(lp.owned_blocks.size());
+    for (uint64_t q = 0; q < ntriples; ++q) {
+        const int dot = (q + 1 == ntriples && want_partials_last) ? DOT_DELTA : DOT_NONE;
+        for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
+            const int64_t b = lp.owned_blocks[k];
+            const int64_t ls = lp.local_start[k];
+            Relax2Block& a = blocks[k];
+            a.in = X + ls;
+            a.mid = nullptr;
+            a.out = U + ls;
+            a.ni = static_cast<int>(topo.ni[b]);
+            a.nj = static_cast<int>(topo.nj[b]);
+            a.omega = opt.omega;
+            a.dyn = dyn_mask[k];
+            a.store_nt = relax2_store_nt ? 1 : 0;
+            a.border = nullptr;
+            a.nborder = 0;
+            a.partials = partials + static_cast<size_t>(poff3[k]) * MAX_PARTIALS;
+        }
+        fence(stream, side, ev_to_side);   // X is complete on the handle's stream
+        profiled([&]() { HIPCHK(launch_relax3_blocks(blocks.data(), rows3.data(), static_cast<int>(blocks.size()), dot, stream)); }, true, stream);
+        HIPCHK(launch_edge_rows(edge_L[0], X, X, PQ, nullptr, M, opt.omega, MODE_RELAX, DOT_NONE, partials, side));
+        HIPCHK(launch_edge_rows(edge_L[1], M, M, PQ, nullptr, M2, opt.omega, MODE_RELAX, DOT_NONE, partials, side));
+        HIPCHK(launch_edge_rows(edge_L[2], M2, M2, PQ, nullptr, U, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(nwg_apply3) * MAX_PARTIALS, side));
+        fence(side, stream, ev_to_main);   // the handle's stream continues behind both
+        std::swap(X, U);
+    }
+}
+
 // want_partials: only the pass whose displacement norms are read back pays for them (the last one of an iterate() call)
 void Smoother::relax_pair(bool want_partials) {
     const int dot = want_partials ? DOT_DELTA : DOT_NONE;
@@ -1224,13 +1339,18 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
 void Smoother::relax_sweeps(uint64_t n, tm_stats& st) {
     int last_nwg = nwg_apply;
     uint64_t k = 0;
-    if (fuse_triples && n >= 3) {   // n = 3 a + 2 b + c, as many triples as possible (n = 4: one triple + one single sweep)
+    if ((fuse_triples || triples_coupled) && n >= 3) {   // n = 3 a + 2 b + c, as many triples as possible (n = 4: one triple + one single sweep)
         const uint64_t ntriples = n / 3;
-        for (uint64_t q = 0; q < ntriples; ++q) relax_triple(q + 1 == ntriples && n % 3 == 0);
+        if (fuse_triples) {
+            for (uint64_t q = 0; q < ntriples; ++q) relax_triple(q + 1 == ntriples && n % 3 == 0);
+            last_nwg = nwg_apply3;
+        } else {
+            relax_triples_coupled(ntriples, n % 3 == 0);
+            last_nwg = nwg_apply3 + edge_L[2].nwg;
+        }
         k = 3 * ntriples;
         st.operator_sweeps += k;
         outer_done += k;
-        last_nwg = nwg_apply3;
     }
     if (fuse_pairs && n - k >= 2) {
         const uint64_t npairs = (n - k) / 2;

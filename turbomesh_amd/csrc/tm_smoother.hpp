@@ -69,6 +69,7 @@ struct Smoother {
     bool use_mg = false;
     void precondition(const double2* in, double2* out);
     double2* M = nullptr;           // X^(k+1) of a fused pair of relax sweeps (perimeter + first-interior ring only)
+    double2* M2 = nullptr;          // coupled triples: X^(k+2) on the perimeter and in the zone next to sides whose perimeter rows move
     bool fuse_pairs = false;
     bool relax2_store_nt = true;     // K2x2 result stores streaming (nt) or plain: by the rank's footprint against the Infinity Cache (create())
     bool pair_sync_events = false;   // TM_PAIR_SYNC=events when the handle was created: multi-rank sweep pairs ordered by events, not device counters
@@ -109,6 +110,13 @@ struct Smoother {
     std::vector<int> poff3, rows3;  // ... and for the three-sweep launches (all perimeter rows fixed)
     int nwg_apply3 = 0;
     bool fuse_triples = false;
+    // Coupled triples (single process): K2x3 with a frozen perimeter stores everything but the nodes within two of a side whose
+    // perimeter rows move; three perimeter-row passes evaluate the perimeter and that zone level by level (rows within 4 / 3 / 2 nodes)
+    bool triples_coupled = false;
+    EdgeRowsDev edge_L[3];
+    double* d_rhs_L[3] = {nullptr, nullptr, nullptr};
+    std::vector<int32_t> order_L[3];
+    std::vector<PlanRow> zone_rows[3];   // KIND_INTERIOR rows of the zones (level 1: distance <= 4, level 2: <= 3, level 3: <= 2)
     bool pipelined_single = false;   // single process, coupled blocks: perimeter-row passes on the chain's queue beside the interior pass
     // halo exchange
     int32_t* d_send_ids = nullptr;
@@ -186,6 +194,7 @@ struct Smoother {
     void relax_sweeps(uint64_t n, tm_stats& st);
     void relax_pair(bool want_partials);
     void relax_triple(bool want_partials);
+    void relax_triples_coupled(uint64_t ntriples, bool want_partials_last);
     void profiled(const std::function<void()>& launch, bool counts = true, hipStream_t on = nullptr);
     void relax2_launch(int subset, bool counts, int dot, hipStream_t on = nullptr, const QueueWait* wait = nullptr);
 };
