@@ -173,3 +173,33 @@ def test_multi_rank_multigrid_preconditioner():
     got = _run_ranks(builder, [0, 1, 0], opt, 3)
     rms = float(np.sqrt(np.mean((mesh_flat(got) - mesh_flat(ref)) ** 2)))
     assert rms <= 2e-10, rms
+
+
+@pytest.mark.parametrize("name,builder,owner", [
+    ("strip3", lambda: configs.strip(3, 40, 300), [0, 1, 2]),
+    ("strip4_reversed", lambda: configs.strip(4, 24, 40, reverse_odd=True), [0, 1, 0, 1]),
+    ("two_by_two", lambda: configs.two_by_two(20, 22), [0, 1, 1, 0]),
+    ("strip2_big", lambda: configs.strip(2, 200, 700, reverse_odd=True), [0, 1]),
+    ("strip3_two_per_rank", lambda: configs.strip(6, 30, 64), [0, 0, 1, 1, 2, 2]),
+])
+def test_multi_rank_sweep_triples_equal_single_rank(name, builder, owner, monkeypatch):
+    # Sweep TRIPLES across ranks (LocalPlan::triple_halo, Smoother::relax_triples_coupled): one exchange of a depth-3 halo per triple,
+    # the perimeter rows, the zone next to them and the ghost rows evaluated level by level with their owners' row definitions.  The
+    # threshold that reserves the schedule for blocks of millions of nodes is lowered for the test (every rank reads the same value).
+    from turbomesh_amd.smoothing import smooth
+
+    opt = solver.Option.hip(inner=solver.Inner.relax)
+    refs = {}
+    for n in (25, 26, 3):
+        ref = builder()
+        smooth.mesh(ref, n, opt)
+        refs[n] = mesh_flat(ref).copy()
+    monkeypatch.setenv("TM_TRIPLES_MIN_NODES", "1")
+    for n in (25, 26, 3):   # 8 triples + a single sweep; 8 triples + a pair; one triple
+        got = _run_ranks(builder, owner, opt, n)
+        a, b = mesh_flat(got), refs[n]
+        assert np.array_equal(a, b), (name, n, float(np.abs(a - b).max()), int(np.any(a != b, axis=1).sum()))
+    got = _run_ranks(builder, owner, opt, 9, rounds=2, hooks_cls=SplitThreadHooks)
+    ref = builder()
+    smooth.mesh(ref, 18, opt)
+    assert np.array_equal(mesh_flat(got), mesh_flat(ref)), name

@@ -11,6 +11,7 @@
 // recomputed on the device from the frozen coordinates every application).
 #include "tm_plan.hpp"
 #include "../../include/tm_hip.h"
+#include <cstdlib>
 #include <algorithm>
 #include <unordered_map>
 
@@ -480,6 +481,19 @@ int64_t LocalPlan::to_local(int64_t gid) const {
     return g == ghost_index.end() ? -1 : n_owned + g->second;
 }
 
+// Sweep triples across ranks pay when the interior pass (three sweeps of a rank's block) outlasts the chain of three perimeter-row
+// passes and an exchange: blocks of several million nodes.  A pure function of the topology (TM_TRIPLES_MIN_NODES overrides the
+// threshold: tests), identical on every rank.
+bool triple_halo_for(const Topology& t, int nranks) {
+    if (nranks < 2) return false;
+    int64_t min_nodes = int64_t{6} << 20;
+    if (const char* e = std::getenv("TM_TRIPLES_MIN_NODES")) min_nodes = std::atoll(e);
+    if (min_nodes < 0) return false;
+    for (int64_t b = 0; b < t.nblocks(); ++b)
+        if (t.ni[b] < 16 || t.nj[b] < 16 || t.ni[b] * t.nj[b] < min_nodes) return false;
+    return true;
+}
+
 LocalPlan build_local_plan(const Topology& t, const std::vector<PlanRow>& all_rows, const std::vector<int32_t>& owner, int rank,
                            int nranks) {
     LocalPlan lp;
@@ -552,6 +566,29 @@ LocalPlan build_local_plan(const Topology& t, const std::vector<PlanRow>& all_ro
         need2[r].erase(std::unique(need2[r].begin(), need2[r].end()), need2[r].end());
     }
     need.swap(need2);
+    // depth 3 (sweep TRIPLES on large coupled blocks, Smoother::relax_triples_coupled): the rows of the depth-2 set are evaluated one
+    // level further down (ghost_rows2: their definitions), and the remote rows THOSE read travel too.  Decided from the topology alone,
+    // so every rank -- and tm_rccl_hooks, which builds its tables from this function as well -- agrees on the exchange lists.
+    lp.triple_halo = triple_halo_for(t, nranks);
+    if (lp.triple_halo) {
+        std::vector<std::vector<std::pair<int32_t, int64_t>>> need3 = need;
+        for (int r = 0; r < nranks; ++r) {
+            for (const auto& pr : need[r]) {
+                const PlanRow def = row_def(pr.second);
+                auto touch = [&](int64_t gid) {
+                    const int32_t o = owner_of_gid(gid);
+                    if (o != r) need3[r].emplace_back(o, gid);
+                };
+                for (int k = 0; k < def.ncols; ++k) touch(def.col[k]);
+                if (def.kind == KIND_SMOOTHED)
+                    for (int k = 0; k < 4; ++k) touch(def.metric[k]);
+                if (r == rank) lp.ghost_rows2.push_back(def);
+            }
+            std::sort(need3[r].begin(), need3[r].end());
+            need3[r].erase(std::unique(need3[r].begin(), need3[r].end()), need3[r].end());
+        }
+        need.swap(need3);
+    }
     for (const auto& pr : need[rank]) {
         lp.ghost_index[pr.second] = static_cast<int64_t>(lp.ghost_gid.size());
         lp.ghost_gid.push_back(pr.second);

@@ -93,6 +93,10 @@ struct LocalPlan {
     // KIND_INTERIOR rows for its first-interior nodes), and the ghost set above also contains every remote row THOSE read.  A pair of
     // relaxation sweeps then needs ONE exchange: X^k of the depth-2 set travels, the depth-1 rows of X^(k+1) are recomputed.
     std::vector<PlanRow> ghost_rows;
+    // Depth-3 halo (triple_halo): ghost_rows2 = the definitions of every row of the depth-2 set; sweep triples evaluate THEM at level 1
+    // and ghost_rows at level 2, and the ghost set holds every remote row those read (X^k of it travels once per triple)
+    bool triple_halo = false;
+    std::vector<PlanRow> ghost_rows2;
     // halo exchange: for peer k, my rows send_ids[send_off[k] .. +send_cnt[k]) (local ids) go to peer_rank[k];
     // its rows land in my ghost segment at [recv_off[k], +recv_cnt[k])
     std::vector<int32_t> peer_rank;
@@ -106,6 +110,7 @@ struct LocalPlan {
     int64_t to_local(int64_t gid) const;    // -1 if neither owned nor ghost
     const Topology* topo = nullptr;
 };
+bool triple_halo_for(const Topology& t, int nranks);
 LocalPlan build_local_plan(const Topology& t, const std::vector<PlanRow>& all_rows, const std::vector<int32_t>& owner, int rank,
                            int nranks);
 

@@ -236,7 +236,10 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     {   // coupled triples: a single process (no neighbouring rank), large blocks, some perimeter row that moves
         bool any_nf = false;
         for (const PlanRow& pr : lp.rows) any_nf = any_nf || pr.kind != KIND_FIXED;
-        triples_coupled = fuse_pairs && any_nf && lp.ghost_gid.empty() && lp.send_ids.empty() && lp.n_owned >= (1 << 21);
+        // ... or several ranks whose blocks are all large enough for the exchange of a depth-3 halo once per triple (LocalPlan::triple_halo,
+        // decided from the topology alone: every rank with a neighbour takes the same schedule)
+        const bool peers = has_hooks && (!lp.ghost_gid.empty() || !lp.send_ids.empty());
+        triples_coupled = fuse_pairs && any_nf && (peers ? lp.triple_halo : lp.n_owned >= (1 << 21));
         for (int64_t b : lp.owned_blocks) triples_coupled = triples_coupled && topo.ni[b] >= 16 && topo.nj[b] >= 16 && relax3_supported(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
         if (const char* e = std::getenv("TM_TRIPLES_COUPLED")) triples_coupled = triples_coupled && std::atoi(e) != 0;
         if (triples_coupled) M2 = vec();
@@ -462,6 +465,10 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
                 std::vector<const PlanRow*> sl;
                 for (size_t k : nf_rows) sl.push_back(&lp.rows[k]);
                 for (const PlanRow& z : zone_rows[lev]) sl.push_back(&z);
+                // several ranks: level 1 also evaluates every row of the depth-2 ghost set, level 2 the depth-1 rows (their owners'
+                // definitions, hence their owners' bits); level 3 reads them
+                if (lev == 0) for (const PlanRow& g : lp.ghost_rows2) sl.push_back(&g);
+                if (lev == 1) for (const PlanRow& g : lp.ghost_rows) sl.push_back(&g);
                 build_table(sl, edge_L[lev], d_rhs_L[lev], order_L[lev]);
             }
         }
@@ -642,7 +649,13 @@ void Smoother::upload(const tm_mesh_desc* mesh) {
     });
     static const double zero_rhs[2] = {0.0, 0.0};   // interior rows have b = 0
     for (int lev = 0; lev < 3; ++lev)
-        put(d_rhs_L[lev], order_L[lev], [&](int32_t k) { return static_cast<size_t>(k) < nf_rows.size() ? &h_rhs[2 * nf_rows[k]] : zero_rhs; });
+        put(d_rhs_L[lev], order_L[lev], [&](int32_t k) -> const double* {
+            const size_t q = static_cast<size_t>(k), nz = zone_rows[lev].size();
+            if (q < nf_rows.size()) return &h_rhs[2 * nf_rows[q]];
+            if (q < nf_rows.size() + nz) return zero_rhs;
+            const std::vector<PlanRow>& g = lev == 0 ? lp.ghost_rows2 : lp.ghost_rows;   // static parts; coordinate parts come from the row's value
+            return g[q - nf_rows.size() - nz].rhs;
+        });
     if (opt.inner == TM_INNER_RELAX) prefill_fixed();
     sync();   // host staging buffers may go away after return
 }
@@ -1162,6 +1175,8 @@ void Smoother::relax_triple(bool want_partials) {
 // level 2 = perimeter of X^(k+2) and the nodes within 3 (from M into M2), level 3 = perimeter of X^(k+3) and the nodes within 2
 // (from M2 into the output).  Interior nodes are evaluated as KIND_INTERIOR rows -- K2's own arithmetic, the same bits -- so the
 // result equals three single sweeps bit for bit; the zone is 0.2 % of a 2048^2 block.  One join of the two queues per triple.
+// Several ranks (LocalPlan::triple_halo): X^k of the depth-3 ghost set travels once per triple in front of level 1, which also
+// evaluates the depth-2 ghost rows, level 2 the depth-1 ones -- with their owners' row definitions, so with their owners' bits.
 void Smoother::relax_triples_coupled(uint64_t ntriples, bool want_partials_last) {
     if (!side) {
         int least = 0, greatest = 0;
@@ -1193,6 +1208,8 @@ void Smoother::relax_triples_coupled(uint64_t ntriples, bool want_partials_last)
         }
         fence(stream, side, ev_to_side);   // X is complete on the handle's stream
         profiled([&]() { HIPCHK(launch_relax3_blocks(blocks.data(), rows3.data(), static_cast<int>(blocks.size()), dot, stream)); }, true, stream);
+        exchange(X, side);                 // several ranks: X^k of the depth-3 ghost set, once per triple (a no-op otherwise)
+        exchange_finish(side);
         HIPCHK(launch_edge_rows(edge_L[0], X, X, PQ, nullptr, M, opt.omega, MODE_RELAX, DOT_NONE, partials, side));
         HIPCHK(launch_edge_rows(edge_L[1], M, M, PQ, nullptr, M2, opt.omega, MODE_RELAX, DOT_NONE, partials, side));
         HIPCHK(launch_edge_rows(edge_L[2], M2, M2, PQ, nullptr, U, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(nwg_apply3) * MAX_PARTIALS, side));
