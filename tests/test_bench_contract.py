@@ -78,7 +78,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("pair_sync", ["counters", "events"])
+@pytest.mark.parametrize("pair_sync", ["counters", "events", "triples"])
 def test_bench_gpus4_config4_rehearsal_on_one_gpu_is_bit_identical_to_one_handle(pair_sync):
     # `python bench.py --gpus 4 --config 4` launches its own ranks; rehearsed on ONE GPU with the gloo transport (halo rows staged
     # through the host; RCCL refuses two ranks on one device): strong scaling of the 8-block strip, 2 blocks per rank, and after
@@ -90,6 +90,9 @@ def test_bench_gpus4_config4_rehearsal_on_one_gpu_is_bit_identical_to_one_handle
     env.pop("TM_PAIR_SYNC", None)
     if pair_sync == "events":
         env["TM_PAIR_SYNC"] = "events"
+    env.pop("TM_TRIPLES_MIN_NODES", None)
+    if pair_sync == "triples":   # sweep triples across ranks (depth-3 halo, one exchange per triple): the threshold lowered to these 96^2 blocks
+        env["TM_TRIPLES_MIN_NODES"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--config", "4", "--size", "96", "--steps", "21", "--warmup", "4",
                         "--verify", "--transport", "torch", "--no-cpu-baseline"], capture_output=True, text=True, timeout=600, cwd=ROOT, env=env)
     assert r.returncode == 0, r.stderr[-3000:]

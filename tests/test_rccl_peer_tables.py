@@ -41,6 +41,8 @@ CASES = [
     ("strip8_2048_world8", lambda: _strip8(), 8, list(range(8))),
     ("strip8_2048_world8_reversed", lambda: _strip8(reverse_odd=True), 8, list(range(8))),
     ("strip8_2048_world3_interleaved", lambda: _strip8(), 3, [0, 1, 2, 0, 1, 2, 0, 1]),
+    ("strip8_4096_world8_triple_halo", lambda: configs.strip(8, 4096, 4096, only_blocks=set()), 8, list(range(8))),
+    ("strip4_4096_world2_triple_halo", lambda: configs.strip(4, 4096, 4096, only_blocks=set(), reverse_odd=True), 2, [0, 0, 1, 1]),
     ("two_by_two_world2", lambda: configs.two_by_two(8, 9, tfi=oracle_tfi), 2, [0, 1, 1, 0]),
     ("two_by_two_world3", lambda: configs.two_by_two(8, 9, tfi=oracle_tfi), 3, [0, 1, 2, 0]),
     ("two_by_two_world4", lambda: configs.two_by_two(8, 9, tfi=oracle_tfi), 4, [0, 1, 2, 3]),
@@ -102,3 +104,21 @@ def test_bad_arguments_are_refused():
     own = (C.c_int32 * 8)(*([0] * 7 + [5]))
     assert _capi.lib().tm_rccl_peer_table_build(md.ref(), own, 0, 2, C.byref(t)) == _capi.TM_E_ARG
     assert _capi.lib().tm_rccl_peer_table_build(md.ref(), own, 2, 2, C.byref(t)) == _capi.TM_E_ARG
+
+
+def test_triple_halo_message_sizes(monkeypatch):
+    # blocks of 6 M nodes and more take sweep TRIPLES across ranks: a depth-3 halo, one exchange per triple -- the solved side of an
+    # interface sends 3 rows, the slaved side 4 (one more than for pairs on either side); below the threshold nothing changes
+    mesh = configs.strip(8, 4096, 4096, only_blocks=set())
+    for r in (0, 3, 7):
+        t = _table(mesh, list(range(8)), r, 8)
+        assert t["direct"]
+        for k, b in enumerate(t["peer"]):
+            assert t["send_cnt"][k] == (4 if b < r else 3) * 4096 and t["recv_cnt"][k] == (3 if b < r else 4) * 4096
+    monkeypatch.setenv("TM_TRIPLES_MIN_NODES", "-1")   # off: the pairs' depth-2 halo
+    t = _table(mesh, list(range(8)), 3, 8)
+    assert [c // 4096 for c in t["send_cnt"]] == [3, 2]
+    monkeypatch.setenv("TM_TRIPLES_MIN_NODES", "1")    # tests: any block of at least 16 x 16
+    small = configs.strip(3, 40, 300, only_blocks=set())
+    t = _table(small, [0, 1, 2], 1, 3)
+    assert [c // 300 for c in t["send_cnt"]] == [4, 3]
