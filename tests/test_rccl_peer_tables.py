@@ -85,16 +85,20 @@ def test_every_send_has_its_receive(name, build, world, owner):
     assert transfers > 0
 
 
-def test_config4_message_sizes():
-    # BASELINE configs[3], one block per GPU: the solved side of an interface sends 2 rows of 2048 nodes (32 KiB each), the slaved
-    # side 3 (depth-2 halo); end ranks have one neighbour
+def test_config4_message_sizes(monkeypatch):
+    # BASELINE configs[3], one block per GPU.  Blocks of half a million nodes and more take sweep TRIPLES: a depth-3 halo, one exchange
+    # per triple -- the solved side of an interface sends 3 rows of 2048 nodes (32 KiB each), the slaved side 4; with pairs
+    # (TM_TRIPLES_MIN_NODES=-1, or smaller blocks) a depth-2 halo per pair: 2 and 3 rows; end ranks have one neighbour
     mesh = _strip8()
-    for r in range(8):
-        t = _table(mesh, list(range(8)), r, 8)
-        assert t["direct"] and t["peer"] == [p for p in (r - 1, r + 1) if 0 <= p < 8]
-        for k, b in enumerate(t["peer"]):
-            assert t["send_cnt"][k] == (3 if b < r else 2) * 2048
-            assert t["recv_cnt"][k] == (2 if b < r else 3) * 2048
+    for triples in (True, False):
+        if not triples:
+            monkeypatch.setenv("TM_TRIPLES_MIN_NODES", "-1")
+        for r in range(8):
+            t = _table(mesh, list(range(8)), r, 8)
+            assert t["direct"] and t["peer"] == [p for p in (r - 1, r + 1) if 0 <= p < 8]
+            for k, b in enumerate(t["peer"]):
+                assert t["send_cnt"][k] == ((4 if b < r else 3) if triples else (3 if b < r else 2)) * 2048
+                assert t["recv_cnt"][k] == ((3 if b < r else 4) if triples else (2 if b < r else 3)) * 2048
 
 
 def test_bad_arguments_are_refused():
@@ -107,8 +111,8 @@ def test_bad_arguments_are_refused():
 
 
 def test_triple_halo_message_sizes(monkeypatch):
-    # blocks of 6 M nodes and more take sweep TRIPLES across ranks: a depth-3 halo, one exchange per triple -- the solved side of an
-    # interface sends 3 rows, the slaved side 4 (one more than for pairs on either side); below the threshold nothing changes
+    # 4096^2 blocks: sweep TRIPLES across ranks, a depth-3 halo, one exchange per triple -- the solved side of an interface sends 3
+    # rows, the slaved side 4 (one more than for pairs on either side)
     mesh = configs.strip(8, 4096, 4096, only_blocks=set())
     for r in (0, 3, 7):
         t = _table(mesh, list(range(8)), r, 8)

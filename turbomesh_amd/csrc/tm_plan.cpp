@@ -481,12 +481,14 @@ int64_t LocalPlan::to_local(int64_t gid) const {
     return g == ghost_index.end() ? -1 : n_owned + g->second;
 }
 
-// Sweep triples across ranks pay when the interior pass (three sweeps of a rank's block) outlasts the chain of three perimeter-row
-// passes and an exchange: blocks of several million nodes.  A pure function of the topology (TM_TRIPLES_MIN_NODES overrides the
-// threshold: tests), identical on every rank.
+// Sweep triples across ranks pay when three sweeps of a rank's block outlast the chain of three perimeter-row passes (and the exchange
+// costs a third less per sweep than with pairs): measured with a transport that moves nothing, rank 1 of 3 (tools/split_path_cost.py,
+// settled clocks), us per sweep triples / pairs: 4096^2 41.3 / 55.4, 2048^2 13.1 / 16.7, 1448^2 10.5 / 12.7, 1024^2 8.0 / 10.1,
+// 724^2 8.3 / 8.4, 512^2 10.0 / 9.1.  A pure function of the topology (TM_TRIPLES_MIN_NODES overrides the threshold: tests, A/B
+// runs; negative = never), identical on every rank.
 bool triple_halo_for(const Topology& t, int nranks) {
     if (nranks < 2) return false;
-    int64_t min_nodes = int64_t{6} << 20;
+    int64_t min_nodes = int64_t{1} << 19;
     if (const char* e = std::getenv("TM_TRIPLES_MIN_NODES")) min_nodes = std::atoll(e);
     if (min_nodes < 0) return false;
     for (int64_t b = 0; b < t.nblocks(); ++b)

@@ -239,7 +239,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         // ... or several ranks whose blocks are all large enough for the exchange of a depth-3 halo once per triple (LocalPlan::triple_halo,
         // decided from the topology alone: every rank with a neighbour takes the same schedule)
         const bool peers = has_hooks && (!lp.ghost_gid.empty() || !lp.send_ids.empty());
-        triples_coupled = fuse_pairs && any_nf && (peers ? lp.triple_halo : lp.n_owned >= (1 << 21));
+        triples_coupled = fuse_pairs && any_nf && (peers ? lp.triple_halo : lp.n_owned >= (1 << 20));
         for (int64_t b : lp.owned_blocks) triples_coupled = triples_coupled && topo.ni[b] >= 16 && topo.nj[b] >= 16 && relax3_supported(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
         if (const char* e = std::getenv("TM_TRIPLES_COUPLED")) triples_coupled = triples_coupled && std::atoi(e) != 0;
         if (triples_coupled) M2 = vec();
@@ -1187,6 +1187,16 @@ void Smoother::relax_triples_coupled(uint64_t ntriples, bool want_partials_last)
         HIPCHK(hipEventCreateWithFlags(&ev_inside[0], hipEventDisableTiming));
         HIPCHK(hipEventCreateWithFlags(&ev_inside[1], hipEventDisableTiming));
     }
+    // Ordering between the two queues inside the loop: counters in device memory and one-wave signal / wait kernels, as in
+    // relax_pairs_pipelined (an event record / wait pair stalls its queue for ~10 us on this part, twice per triple: at 2048^2 that is
+    // a third of the interior pass); events when several multi-rank handles share the process or TM_PAIR_SYNC=events asks for them.
+    // A waiter's producer is always enqueued before it in host order.
+    const bool use_flags = !pair_sync_events && g_multirank_handles.load() <= 1;
+    uint32_t* chain_done = sync_flags;        // level-3 passes completed (side queue)
+    uint32_t* inside_done = sync_flags + 1;   // K2x3 passes completed (handle's stream)
+    uint32_t* sync_err = sync_flags + 2;
+    if (use_flags) HIPCHK(hipMemsetAsync(sync_flags, 0, sizeof(uint32_t) * 4, stream));
+    fence(stream, side, ev_to_side);   // X (and the cleared counters) complete on the handle's stream
     std::vector<Relax2Block> blocks(lp.owned_blocks.size());
     for (uint64_t q = 0; q < ntriples; ++q) {
         const int dot = (q + 1 == ntriples && want_partials_last) ? DOT_DELTA : DOT_NONE;
@@ -1206,15 +1216,34 @@ void Smoother::relax_triples_coupled(uint64_t ntriples, bool want_partials_last)
             a.nborder = 0;
             a.partials = partials + static_cast<size_t>(poff3[k]) * MAX_PARTIALS;
         }
-        fence(stream, side, ev_to_side);   // X is complete on the handle's stream
+        // handle's stream: K2x3 of triple q needs the chain of triple q-1 (its level 3 wrote rows of X)
+        if (q > 0) {
+            if (use_flags) HIPCHK(launch_queue_wait(chain_done, static_cast<uint32_t>(q), sync_err, stream));
+            else HIPCHK(hipStreamWaitEvent(stream, ev_to_main, 0));
+        }
         profiled([&]() { HIPCHK(launch_relax3_blocks(blocks.data(), rows3.data(), static_cast<int>(blocks.size()), dot, stream)); }, true, stream);
+        if (use_flags) HIPCHK(launch_queue_signal(inside_done, stream));
+        else HIPCHK(hipEventRecord(ev_inside[q & 1], stream));
+        // chain: the levels of triple q read X: K2x3 of triple q-1 must be complete (its own level 3 precedes them in this queue)
+        if (q > 0) {
+            if (use_flags) HIPCHK(launch_queue_wait(inside_done, static_cast<uint32_t>(q), sync_err, side));
+            else HIPCHK(hipStreamWaitEvent(side, ev_inside[(q - 1) & 1], 0));
+        }
         exchange(X, side);                 // several ranks: X^k of the depth-3 ghost set, once per triple (a no-op otherwise)
         exchange_finish(side);
         HIPCHK(launch_edge_rows(edge_L[0], X, X, PQ, nullptr, M, opt.omega, MODE_RELAX, DOT_NONE, partials, side));
         HIPCHK(launch_edge_rows(edge_L[1], M, M, PQ, nullptr, M2, opt.omega, MODE_RELAX, DOT_NONE, partials, side));
         HIPCHK(launch_edge_rows(edge_L[2], M2, M2, PQ, nullptr, U, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(nwg_apply3) * MAX_PARTIALS, side));
-        fence(side, stream, ev_to_main);   // the handle's stream continues behind both
+        if (q + 1 < ntriples) {
+            if (use_flags) HIPCHK(launch_queue_signal(chain_done, side));
+            else HIPCHK(hipEventRecord(ev_to_main, side));
+        }
         std::swap(X, U);
+    }
+    fence(side, stream, ev_to_main);   // the handle's stream continues behind the whole chain
+    if (use_flags) {
+        HIPCHK(hipMemcpyAsync(h_flags, sync_flags, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, stream));
+        flags_pending = true;
     }
 }
 
