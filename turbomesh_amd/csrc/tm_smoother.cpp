@@ -595,7 +595,8 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     HIPCHK(hipMemsetAsync(S_buf[0], 0, sizeof(KrylovScalars), stream));
     if (S_buf[1] != S_buf[0]) HIPCHK(hipMemsetAsync(S_buf[1], 0, sizeof(KrylovScalars), stream));
     HIPCHK(hipMemsetAsync(sync_flags, 0, sizeof(uint32_t) * 64, stream));
-    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_flags), sizeof(uint32_t) * 4, hipHostMallocDefault));
+    HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_flags), sizeof(uint32_t) * 8, hipHostMallocDefault));   // [0..3] pairs, [4..7] triples
+    std::memset(h_flags, 0, sizeof(uint32_t) * 8);
     for (double2* q : {p_hat, s_hat, mg_w0, mg_w1})
         if (q) HIPCHK(hipMemsetAsync(q, 0, sizeof(double2) * n_local, stream));
     if (PQ) HIPCHK(hipMemsetAsync(PQ, 0, sizeof(double2) * n_local, stream));
@@ -1242,7 +1243,7 @@ void Smoother::relax_triples_coupled(uint64_t ntriples, bool want_partials_last)
     }
     fence(side, stream, ev_to_main);   // the handle's stream continues behind the whole chain
     if (use_flags) {
-        HIPCHK(hipMemcpyAsync(h_flags, sync_flags, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, stream));
+        HIPCHK(hipMemcpyAsync(h_flags + 4, sync_flags, sizeof(uint32_t) * 4, hipMemcpyDeviceToHost, stream));   // (the pairs behind a triple reuse the counters)
         flags_pending = true;
     }
 }
@@ -1430,7 +1431,9 @@ void Smoother::relax_sweeps(uint64_t n, tm_stats& st) {
         sync();
         if (flags_pending) {
             flags_pending = false;
-            if (h_flags[2] != 0) throw TmError(TM_E_HIP, "a device-side dependency between the interior and the border pass was not met within its time limit");
+            const bool timed_out = h_flags[2] != 0 || h_flags[6] != 0;
+            h_flags[2] = h_flags[6] = 0;
+            if (timed_out) throw TmError(TM_E_HIP, "a device-side dependency between the interior pass and the chain of a sweep pair / triple was not met within its time limit");
         }
         st.last_dx2 = h_red[0];
         st.last_dy2 = h_red[1];
