@@ -16,6 +16,7 @@ mkdir -p gpurun_out
   echo "## shader clock / power while the pass runs (tools/dev/clock_probe.py)"
   python3 tools/dev/clock_probe.py 3 2>/dev/null | tail -4 | cut -c1-400
   echo "## STREAM-style copy variants, 256 MiB and 64 MiB per array, alternating direction (tools/ubench/stream.hip)"
+  [ -x tools/ubench/stream_bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -o tools/ubench/stream_bin tools/ubench/stream.hip 2>/dev/null
   if [ -x tools/ubench/stream_bin ]; then ./tools/ubench/stream_bin 256 1 | grep -E "MiB|grid  *8192|hipMemcpy"; ./tools/ubench/stream_bin 64 1 | grep -E "MiB|grid  *8192|hipMemcpy"; fi
   echo "## one rank of a strip, transport that moves nothing (tools/split_path_cost.py), signal / wait kernels"
   for n in 4096 2048 1024; do python3 tools/split_path_cost.py $n 2>/dev/null | grep Native; done
