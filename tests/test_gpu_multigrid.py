@@ -172,6 +172,41 @@ def test_two_operator_applications_per_pass_are_bit_identical(shape, monkeypatch
     assert np.array_equal(out[0][0], out[1][0]), float(np.abs(out[0][0] - out[1][0]).max())
 
 
+RESTRICT_SHAPES = [(2049, 2049), (2050, 2307), (4100, 1200), (2305, 2052)]
+
+
+@pytest.mark.parametrize("shape", RESTRICT_SHAPES, ids=[f"{a}x{b}" for a, b in RESTRICT_SHAPES])
+def test_restriction_folded_into_the_pre_pass_is_bit_identical(shape, monkeypatch):
+    # levels that fill the device: the full weighting rides behind the PRE pass's residual (58-column strips, the residual never
+    # stored) -- k_mg_restrict's nine products in k_mg_restrict's order, so the same bits as the two kernels (TM_MG_RESTRICT_FUSED=0).
+    # Shapes: odd / even sizes in either direction (the short last coarse cell), strip seams at columns 58 k, chunk seams at rows 18 k.
+    out = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("TM_MG_RESTRICT_FUSED", fused)
+        mesh = configs.single_block(shape[0], shape[1], perturb=0.25)
+        with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-12, max_inner=200, check_every=1)) as sm:
+            st = sm.iterate(1)
+            sm.download()
+        assert st["not_converged"] == 0
+        out.append((mesh.blocks[0].points.data.copy(), st["inner_iterations"]))
+    assert out[0][1] == out[1][1]
+    assert np.array_equal(out[0][0], out[1][0]), float(np.abs(out[0][0] - out[1][0]).max())
+
+
+def test_folded_restriction_with_a_control_function(monkeypatch):
+    # the (P, Q) flavour: a White plate of two 2049 x 2100 blocks
+    out = []
+    for fused in ("1", "0"):
+        monkeypatch.setenv("TM_MG_RESTRICT_FUSED", fused)
+        mesh = configs.plate(2049, 2100)
+        with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-10, max_inner=60, check_every=1), wcf.Algorithm(wcf.White(0.02))) as sm:
+            st = sm.iterate(1)
+            sm.download()
+        out.append((mesh_flat(mesh), st["inner_iterations"]))
+    assert out[0][1] == out[1][1]
+    assert np.array_equal(out[0][0], out[1][0])
+
+
 def test_two_per_pass_with_a_control_function_and_many_blocks(monkeypatch):
     # the (P, Q) flavours (White plate) and multi-block meshes with stretched cells (T106: 8 blocks, semi-coarsened levels)
     for build, control in ((TOPOLOGIES["plate_le"], wcf.Algorithm(wcf.White(0.02))), (lambda: load("T106", None)[1], None)):

@@ -312,11 +312,16 @@ struct MgPairArgs {
     double2* out = nullptr;
     double2* out2 = nullptr;          // kind 1
     const double2* coarse = nullptr;  // kind 0 with the prolongation folded in
+    // kind 1 with the restriction folded in (mg_pair_restrict_supported): the coarse level's frozen field and its right-hand side;
+    // out2 is then not written
+    const double2* xc = nullptr;
+    double2* fc = nullptr;
     int nic = 0, njc = 0, ci = 0, cj = 0;
     int ni = 0, nj = 0;
     double omega = 1.0;
 };
 bool mg_pair_supported(int ni, int nj);
+bool mg_pair_restrict_supported(int ni, int nj, int ci, int cj);
 hipError_t launch_mg_pair(const MgPairArgs& a, int kind, hipStream_t stream);
 // e_fine += bilinear interpolation of e_coarse, interior fine nodes
 hipError_t launch_mg_prolong_add(const double2* e_coarse, double2* e_fine, const MgPair& g, hipStream_t stream);

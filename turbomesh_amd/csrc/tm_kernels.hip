@@ -1131,6 +1131,7 @@ hipError_t launch_relax3_blocks(const Relax2Block* blocks, const int* rows_per_c
 // POST 64 B/node instead of 128 (68 instead of 132 with the prolongation), PRE 64 instead of 112.
 // The error is zero on the block perimeter (tm_multigrid.hpp): the intermediate stage is forced to zero there.
 // ------------------------------------------------------------------------------------------
+constexpr int MG_RST_W = 58;   // columns per strip of the PRE pass that also restricts
 struct MgMetric {
     double G11, G22, mhG12, m2D, D, rinv;
 };
@@ -1168,8 +1169,9 @@ __device__ __forceinline__ double2 mg_scaled_row(const MgMetric& g, const Row3& 
     return make_double2(sx * g.rinv, sy * g.rinv);
 }
 
-template <int KIND, bool HAS_PQ, bool PRO, int U>
+template <int KIND, bool HAS_PQ, bool PRO, bool RST, int U>
 __device__ __forceinline__ void mg_pair_strip(const MgPairArgs& a, const Relax2Tile& t) {
+    static_assert(!RST || KIND == 1, "the restriction rides behind the residual");
     const int ni = a.ni, nj = a.nj;
     const int cc = min(max(t.c, 0), nj - 1);
     const double2 zero = make_double2(0.0, 0.0);
@@ -1220,6 +1222,7 @@ __device__ __forceinline__ void mg_pair_strip(const MgPairArgs& a, const Relax2T
     double2 Xc[3], Xe_cur;
     MgMetric Mp = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
     double2 f_prev = zero, pq_prev = zero;
+    double2 rm2 = zero, rm1 = zero;   // RST: the residual of the two rows above
     Ld cur[U], nxt[U];
     {   // warm-up: rows i0-2, i0-1 of `in` and of the frozen field
         Ld w0, w1;
@@ -1236,7 +1239,7 @@ __device__ __forceinline__ void mg_pair_strip(const MgPairArgs& a, const Relax2T
         S[0] = S[1] = S[2] = A[2];
         Xc[2] = zero;
     }
-    const int nsteps = nrows + 2;
+    const int nsteps = nrows + (RST ? 3 : 2);   // RST: the residual of row i1 too (the last coarse row of the chunk averages it)
     auto group = [&](const int tb) {
 #pragma unroll
         for (int u = 0; u < U; ++u) load_step(t.i0 - 2 + tb + U + u, nxt[u]);
@@ -1278,9 +1281,44 @@ __device__ __forceinline__ void mg_pair_strip(const MgPairArgs& a, const Relax2T
                 const double aii = -0.5 * Mp.D;
                 o = make_double2(aii * res2.x, aii * res2.y);
             }
-            const bool live = t.out_lane && (i >= t.i0) && (i < t.i1);
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, o), out2_rsrc,
-                                                   static_cast<int>(live ? lane_off + static_cast<unsigned>((i - t.i0) * nj * 16) : OOB_VOFFSET), 0, 2);
+            if (!RST) {
+                const bool live = t.out_lane && (i >= t.i0) && (i < t.i1);
+                __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, o), out2_rsrc,
+                                                       static_cast<int>(live ? lane_off + static_cast<unsigned>((i - t.i0) * nj * 16) : OOB_VOFFSET), 0, 2);
+            } else {
+                // Full weighting behind the residual (k_mg_restrict's sums in k_mg_restrict's order, so the same bits): the residual
+                // is never stored.  Chunks start on odd rows and hold an even number of them, strips start on even columns: the
+                // coarse node (ci, cj) sits on the even row 2 ci / even lane of column 2 cj, and its 3 x 3 is complete when the odd
+                // row below it leaves stage 2.  The array the unfused kernel reads is zero on the level's perimeter.
+                const double2 oz = (col_in && i >= 1 && i <= ni - 2) ? o : zero;
+                if ((i & 1) && i > t.i0 && i <= t.i1) {   // wave-uniform
+                    double2 acc = zero;
+                    auto row_sum = [&](const double2 v, const double wi) {
+                        const double2 l = lane_prev0(v), r = lane_next0(v);
+                        acc.x = fma(wi * 0.25, l.x, acc.x);
+                        acc.y = fma(wi * 0.25, l.y, acc.y);
+                        acc.x = fma(wi * 0.5, v.x, acc.x);
+                        acc.y = fma(wi * 0.5, v.y, acc.y);
+                        acc.x = fma(wi * 0.25, r.x, acc.x);
+                        acc.y = fma(wi * 0.25, r.y, acc.y);
+                    };
+                    row_sum(rm2, 0.25);
+                    row_sum(rm1, 0.5);
+                    row_sum(oz, 0.25);
+                    const int ci = (i - 1) >> 1, cj = t.c >> 1, lane = t.c - t.c0 + 2;
+                    const bool emit = !(t.c & 1) && lane >= 4 && lane <= 60 && t.c >= 2 && t.c <= nj - 2 && ci >= 1 && ci <= a.nic - 2 && cj <= a.njc - 2;
+                    if (emit) {
+                        const size_t oc = static_cast<size_t>(ci) * a.njc + cj;
+                        const double2 xp = a.xc[oc + a.njc], xm = a.xc[oc - a.njc], xr = a.xc[oc + 1], xl = a.xc[oc - 1];
+                        const double dxx = xp.x - xm.x, dxy = xp.y - xm.y, dex = xr.x - xl.x, dey = xr.y - xl.y;
+                        const double aic = -0.5 * (fma(dxx, dxx, dxy * dxy) + fma(dex, dex, dey * dey));
+                        const double k = 16.0 / ((aic == 0.0) ? 1.0 : aic);
+                        a.fc[oc] = make_double2(k * acc.x, k * acc.y);
+                    }
+                }
+                rm2 = rm1;
+                rm1 = oz;
+            }
             Mp = M;
             f_prev = fq;
             if (HAS_PQ) pq_prev = L.pq;
@@ -1293,7 +1331,7 @@ __device__ __forceinline__ void mg_pair_strip(const MgPairArgs& a, const Relax2T
     for (int tb = U; tb < nsteps; tb += U) group(tb);
 }
 
-template <int KIND, bool HAS_PQ, bool PRO>
+template <int KIND, bool HAS_PQ, bool PRO, bool RST = false>
 __global__ __launch_bounds__(256) void k_mg_pair(MgPairArgs a, int RI, int nSG, int nRC) {
     const int lane = threadIdx.x & 63;
     const int wave = threadIdx.x >> 6;
@@ -1303,17 +1341,33 @@ __global__ __launch_bounds__(256) void k_mg_pair(MgPairArgs a, int RI, int nSG, 
     const int rc = logical / nSG;
     const int sg = logical - rc * nSG;
     Relax2Tile t;
-    t.c0 = (sg * 4 + wave) * 60;
+    // RST: 58-column strips on lanes 3..60 -- a coarse node needs the residual of the lanes either side of its own
+    t.c0 = (sg * 4 + wave) * (RST ? MG_RST_W : 60);
     t.c = t.c0 - 2 + lane;
-    t.out_lane = (lane >= 2) && (lane <= 61) && (t.c >= 1) && (t.c <= a.nj - 2);
+    t.out_lane = (lane >= (RST ? 3 : 2)) && (lane <= (RST ? 60 : 61)) && (t.c >= 1) && (t.c <= a.nj - 2);
     t.i0 = 1 + rc * RI;
     t.i1 = min(t.i0 + RI, a.ni - 1);
-    if (t.c0 <= a.nj - 2 && t.i0 < t.i1) mg_pair_strip<KIND, HAS_PQ, PRO, 3>(a, t);   // wave-uniform
+    if (t.c0 + (RST ? 1 : 0) <= a.nj - 2 && t.i0 < t.i1) mg_pair_strip<KIND, HAS_PQ, PRO, RST, 3>(a, t);   // wave-uniform
 }
 
 bool mg_pair_supported(int ni, int nj) { return ni >= 5 && nj >= 5 && nj <= (1 << 20); }
+// The restriction folded into the PRE pass: levels coarsened in both directions that fill the device with 18-row chunks (the
+// coarser ones are launch-bound either way and keep the two kernels)
+bool mg_pair_restrict_supported(int ni, int nj, int ci, int cj) {
+    if (!mg_pair_supported(ni, nj) || !ci || !cj) return false;
+    const int nstrips = (nj - 2 + MG_RST_W - 1) / MG_RST_W, nSG = (nstrips + 3) / 4;
+    return static_cast<long>(nSG) * ((ni - 2 + 17) / 18) >= 1024;
+}
 hipError_t launch_mg_pair(const MgPairArgs& a, int kind, hipStream_t st) {
     if (!mg_pair_supported(a.ni, a.nj)) return hipErrorInvalidValue;
+    if (kind == 1 && a.fc) {
+        if (!mg_pair_restrict_supported(a.ni, a.nj, a.ci, a.cj) || !a.xc) return hipErrorInvalidValue;
+        const int nstrips = (a.nj - 2 + MG_RST_W - 1) / MG_RST_W, nSG = (nstrips + 3) / 4, RI = 18, nRC = (a.ni - 2 + RI - 1) / RI;
+        const dim3 grid(nSG * nRC), block(256);
+        if (a.pq) hipLaunchKernelGGL((k_mg_pair<1, true, false, true>), grid, block, 0, st, a, RI, nSG, nRC);
+        else hipLaunchKernelGGL((k_mg_pair<1, false, false, true>), grid, block, 0, st, a, RI, nSG, nRC);
+        return hipGetLastError();
+    }
     const int nstrips = (a.nj - 1 + 59) / 60, nSG = (nstrips + 3) / 4, interior = a.ni - 2;
     int RI = 18;   // like K2x2: short chunks, and shorter still while the level cannot fill the device
     while (RI > 3 && static_cast<long>(nSG) * ((interior + RI - 1) / RI) < 1024) RI -= 3;
@@ -2273,7 +2327,7 @@ __device__ __forceinline__ void scalar_update_body(KrylovScalars* S, const doubl
         S->rho_old[c] = 1.0;
         S->alpha[c] = 1.0;
         S->omega[c] = 1.0;
-        S->beta[c] = rr;   // (rho/rho_old) * (alpha/omega); p = v = 0 so p <- r anyway
+        S->beta[c] = 0.0;   // p <- r (k_p_update selects on it: p and v need not be cleared; the fused forms multiply cleared arrays)
         S->early[c] = 0;
         const bool done = !(rr > S->tol2[c]);
         S->done[c] = done ? 1 : 0;
@@ -2438,7 +2492,8 @@ __global__ __launch_bounds__(VEC_BLOCK) void k_p_update(LazyScalars L, const dou
 #pragma unroll
         for (int q = 0; q < VEC_UNROLL; ++q) {
             const int64_t i = i0 + q * stride;
-            if (i < n) store_nt(p + i, make_double2(ri[q].x + bx * (pi[q].x - ox * vi[q].x), ri[q].y + by * (pi[q].y - oy * vi[q].y)));   // BiCGStab.zig:310-312
+            // BiCGStab.zig:310-312; beta = 0 (the first iteration, a finished component): p = r whatever p and v hold
+            if (i < n) store_nt(p + i, make_double2(bx == 0.0 ? ri[q].x : ri[q].x + bx * (pi[q].x - ox * vi[q].x), by == 0.0 ? ri[q].y : ri[q].y + by * (pi[q].y - oy * vi[q].y)));
         }
     }
 }

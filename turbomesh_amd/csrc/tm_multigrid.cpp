@@ -46,6 +46,7 @@ void BlockMG::build(DeviceArena& arena, int ni, int nj, bool has_pq, double aspe
         fuse_prolong_min = std::atoi(e) == 2 ? 0 : fuse_prolong_min;
     }
     if (const char* e = std::getenv("TM_MG_PAIR")) use_pair = std::atoi(e) != 0;   // 0: the one-sweep-per-pass kernels everywhere (A/B runs, bit-identity tests)
+    if (const char* e = std::getenv("TM_MG_RESTRICT_FUSED")) fuse_restrict = std::atoi(e) != 0;
     L.clear();
     MgLevel l0;
     l0.ni = ni;
@@ -175,9 +176,22 @@ void BlockMG::vcycle(const double2* f0, double2* z, double2* w0, double2* w1, hi
             a.ni = L[l].ni;
             a.nj = L[l].nj;
             a.omega = omega;
+            const MgPair g = pair(l);
+            if (fuse_restrict && mg_pair_restrict_supported(a.ni, a.nj, g.ci, g.cj)) {   // ... and the restriction behind the residual
+                a.out2 = nullptr;
+                a.xc = L[l + 1].X;
+                a.fc = L[l + 1].f;
+                a.nic = g.nic;
+                a.njc = g.njc;
+                a.ci = g.ci;
+                a.cj = g.cj;
+                HIPCHK(launch_mg_pair(a, 1, st));
+                std::swap(cur[l], oth[l]);
+                continue;
+            }
             HIPCHK(launch_mg_pair(a, 1, st));
             std::swap(cur[l], oth[l]);
-            HIPCHK(launch_mg_restrict(L[l].r, L[l + 1].X, L[l + 1].f, pair(l), st));
+            HIPCHK(launch_mg_restrict(L[l].r, L[l + 1].X, L[l + 1].f, g, st));
             continue;
         }
         if (nu_pre >= 2) {   // sweeps 1 and 2 from e = 0 in one pass over f (K2, MODE_MG_FIRST2); it lands where scale + one sweep would

@@ -31,6 +31,7 @@ class BlockMG {
     int64_t fuse_prolong_min = 262144;   // nodes of a level from which the folded form is used
     bool fuse_prolong = true;   // the prolongation formed inside the first post-smoothing sweep (launch_mg_prolong_smooth); TM_MG_FUSE_PROLONG=0: k_mg_prolong_add
     double omega = 0.8;
+    bool fuse_restrict = true;   // levels that fill the device: the full weighting rides behind the PRE pass's residual, which is never stored (TM_MG_RESTRICT_FUSED=0: off)
     bool use_pair = true;   // two operator applications per pass on every level of at least 5 x 5 nodes (k_mg_pair); TM_MG_PAIR=0: off
     // level 0 buffers are the caller's; coarser levels are carved from the arena
     // aspect = mean g11/g22 of the block's cells (1 = unknown / isotropic); worst_case = size the arena for any aspect

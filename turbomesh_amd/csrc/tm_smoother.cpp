@@ -983,8 +983,7 @@ int Smoother::picard_bicgstab(tm_stats& st) {
     if (use_mg)   // level hierarchy of the newly frozen field
         for (size_t k = 0; k < lp.owned_blocks.size(); ++k) mg[k].set_field(X + lp.local_start[k], PQ ? PQ + lp.local_start[k] : nullptr, stream);
     // warm start: the solution vector starts from the current coordinates (BiCGStab.zig:136-153; later
-    // outer iterations continue from the copied-back solution, which is the same field)
-    HIPCHK(hipMemcpyAsync(U, X, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));
+    // outer iterations continue from the copied-back solution, which is the same field) -- copied behind the stop test below
     // tolerance from ||D^-1 b||
     HIPCHK(launch_edge_rhs(edge, X, PQ, nullptr, 1, partials, stream));
     reduce_update(edge.nwg, STEP_TOL, (opt.flags & TM_OPT_RTOL_INITIAL) ? -opt.rtol : opt.rtol, opt.atol);
@@ -994,8 +993,8 @@ int Smoother::picard_bicgstab(tm_stats& st) {
     bool converged = false;
     poll_iters = 0;
     while (true) {
-        // r = D^-1 (b - A U) ; r_hat = r ; p = v = 0
-        apply(U, r, MODE_RESID, DOT_OUT2, nullptr, X, 0.0, fuse2 ? STEP_INIT2 : STEP_INIT);
+        // r = D^-1 (b - A U) ; r_hat = r ; p = v = 0   (first pass: U is X)
+        apply(restarts == 0 ? X : U, r, MODE_RESID, DOT_OUT2, nullptr, X, 0.0, fuse2 ? STEP_INIT2 : STEP_INIT);
         st.operator_sweeps += 1;
         if (restarts == 0) {   // scaled nonlinear residual of this outer iteration
             flush_pending();
@@ -1004,14 +1003,18 @@ int Smoother::picard_bicgstab(tm_stats& st) {
             st.scaled_residual_rms = std::sqrt((h_S->rr0[0] + h_S->rr0[1]) / (2.0 * static_cast<double>(dof_global)));
             if (stop_tol > 0.0 && st.scaled_residual_rms <= stop_tol) return 2;   // X already satisfies A(X) X = b to stop_tol: leave it untouched
             if (h_S->done[0] == 1 && h_S->done[1] == 1) {
+                HIPCHK(hipMemcpyAsync(U, X, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));   // the copy-back below reads it
                 converged = true;
                 break;
             }
         }
         // (behind the stop test: an outer iteration that finds its system already solved moves no vector at all)
+        if (restarts == 0) HIPCHK(hipMemcpyAsync(U, X, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));
         HIPCHK(hipMemcpyAsync(r_hat, r, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));
-        HIPCHK(hipMemsetAsync(p, 0, sizeof(double2) * n_local, stream));
-        HIPCHK(hipMemsetAsync(v, 0, sizeof(double2) * n_local, stream));
+        if (fuse2 || fuse_p) {   // the fused forms multiply p and v by beta = 0 in their first pass; k_p_update selects instead
+            HIPCHK(hipMemsetAsync(p, 0, sizeof(double2) * n_local, stream));
+            HIPCHK(hipMemsetAsync(v, 0, sizeof(double2) * n_local, stream));
+        }
         if (fuse2) HIPCHK(hipMemsetAsync(t, 0, sizeof(double2) * n_local, stream));   // the first pass multiplies it by omega = 0
         bool breakdown = false;
         poll_open = false;
