@@ -495,7 +495,7 @@ def main():
         # sweeps it performs on the way (K2x2: two, K2x3: three).  achieved / peak is therefore a true bandwidth fraction, <= 1.
         bytes_per_launch = BYTES_PER_NODE * nodes_rank
         achieved = bytes_per_launch / k2_avg_s / 1e9
-        traffic, traffic_src = None, None
+        traffic, traffic_src, valu_insts = None, None, None
         tpath = os.path.join(ROOT, "profiles", "traffic.json")   # written by tools/pmc_traffic.py from separate rocprofv3 --pmc passes
         if os.path.exists(tpath) and args.config == 2 and world == 1:
             try:
@@ -503,6 +503,7 @@ def main():
                 if tj.get("n") == n and tj.get("kernel", "k_apply") == kname:
                     stale = tj.get("kernels_hash") not in (None, kernels_hash())
                     traffic = None if stale else tj.get("hbm_bytes_per_launch")
+                    valu_insts = None if stale else tj.get("valu_wave_insts_per_launch")
                     traffic_src = ("profiles/traffic.json: rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate passes of an earlier run of this command"
                                    + (f", {tj.get('date')}" if tj.get("date") else "") + ("; STALE (kernel source changed since), dropped" if stale else ""))
             except Exception:
@@ -533,6 +534,18 @@ def main():
                               "achieved_GBps": BYTES_PER_NODE * n * n / (us1 * 1e-6) / 1e9, "frac": BYTES_PER_NODE * n * n / (us1 * 1e-6) / 1e9 / HBM_PEAK_GBPS}
             except Exception as e:   # noqa: BLE001
                 print(f"[bench] single-sweep reference failed: {e}", file=sys.stderr)
+        # The pass is bound by fp64 ISSUE, not by bytes: price the same launch time against the vector unit as well.  A wave64 fp64 (or
+        # DPP) instruction occupies a SIMD for 4 cycles: 256 CUs x 4 SIMDs x 2.4 GHz / 4 = 614.4 G wave-instructions/s -- the figure behind
+        # the part's 78.6 TFLOP/s fp64 vector peak (MI355X_MICROARCH.md).  Instructions per launch: SQ_INSTS_VALU of a separate --pmc pass.
+        valu = None
+        if valu_insts:
+            peak_ginst = 256 * 4 * 2.4 / 4.0
+            ach = valu_insts / k2_avg_s / 1e9
+            valu = {"wave_instructions_per_launch": valu_insts, "achieved_Ginst_per_s": ach, "peak_Ginst_per_s": peak_ginst, "frac": ach / peak_ginst,
+                    "per_node_and_sweep": valu_insts * 64.0 / (nodes_rank * spl),
+                    "what": ("VALU wave-instructions (SQ_INSTS_VALU, profiles/traffic.json, same kernel source) / this run's launch time, against the issue peak at the "
+                             "2.4 GHz specification clock; the pass runs at ~2.0 GHz under the 1400 W cap, where the same count is ~0.8 of what can issue; "
+                             "the reciprocal (v_rcp_f64) issues at a quarter of that rate, so the pipes are busier than the instruction count says")}
         out = {
             "metric": f"nodes smoothed/sec (elliptic sweeps, {n}^2 blocks) + achieved HBM GB/s",
             "value": value, "unit": "nodes/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
@@ -547,6 +560,7 @@ def main():
                        "sweep_equiv_GBps_whole_job": BYTES_PER_NODE * value / 1e9},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src,
+                         "valu_issue": valu,
                          "single_sweep_reference": single_ref,
                          "stream_ceiling_GBps": (max(stream.values()) if stream else None),
                          "frac_of_stream": (achieved / max(stream.values()) if stream else None),

@@ -5,7 +5,10 @@
 gfx950 corrections applied as that guide prescribes: FETCH_SIZE and WRITE_SIZE are in KiB; FETCH_SIZE reports exactly
 half of the bytes of a wide (16 B/lane) coalesced streaming read -> doubled; WRITE_SIZE is exact for 16 B/lane streaming stores.
 
-usage: pmc_traffic.py <dir with FETCH_SIZE run> <dir with WRITE_SIZE run> <n> <out.json> [kernel substring = k_relax3] [sweeps per launch = 3]"""
+A third, optional pass with the SQ counters (SQ_INSTS_VALU ...) adds the VALU wave-instructions per launch: the pass the bench
+times is bound by fp64 issue, and bench.py prices its launch time against the issue peak as well (roofline.valu_issue).
+
+usage: pmc_traffic.py <dir with FETCH_SIZE run> <dir with WRITE_SIZE run> <n> <out.json> [kernel substring = k_relax3] [sweeps per launch = 3] [dir with SQ run]"""
 import csv
 import datetime
 import glob
@@ -47,5 +50,13 @@ if __name__ == "__main__":
         "date": datetime.date.today().isoformat(),
         "corrections": "FETCH_SIZE x2 (gfx950 reports half of a wide coalesced read), KiB -> bytes; separate --pmc passes",
     }
+    if len(sys.argv) > 7 and os.path.isdir(sys.argv[7]):
+        try:
+            insts, ns = mean_counter(sys.argv[7], "SQ_INSTS_VALU", kern)
+            res["valu_wave_insts_per_launch"] = insts
+            res["valu_launches_sampled"] = ns
+            res["avg_kernel_us_under_pmc"].append(mean_duration_us(sys.argv[7], kern))
+        except (IndexError, ZeroDivisionError):
+            pass
     json.dump(res, open(out, "w"), indent=1)
     print(json.dumps(res))

@@ -23,6 +23,6 @@ cp "$out"/pmc_sq/p_counter_collection.csv "$out/${tag}_pmc_sq_k2x3_counter_colle
 cp "$out"/pmc_fetch/p_counter_collection.csv "$out/${tag}_pmc_fetch_counter_collection.csv" 2>/dev/null
 cp "$out"/pmc_write/p_counter_collection.csv "$out/${tag}_pmc_write_counter_collection.csv" 2>/dev/null
 cd "$root"
-python3 tools/pmc_traffic.py "$out/pmc_fetch" "$out/pmc_write" 4096 "$out/traffic.json" > /dev/null
+python3 tools/pmc_traffic.py "$out/pmc_fetch" "$out/pmc_write" 4096 "$out/traffic.json" k_relax3 3 "$out/pmc_sq" > /dev/null
 grep -h '^{' "$out/bench4096_k2x3.out" > "$out/${tag}_bench_n1_under_rocprof.json"
 ls "$out"
