@@ -211,6 +211,13 @@ def test_block_larger_than_two_gibibytes_per_vector():
         sm.download()
     check(fresh.blocks[0].points.data, 1)
     del fresh
+    fresh = configs.single_block(ni, nj)
+    with smooth.Smoother(fresh, _relax(False)) as sm:     # K2x3: one triple
+        sm.iterate(3)
+        sm.download()
+    check(fresh.blocks[0].points.data, 3)
+    assert np.array_equal(fresh.blocks[0].points.data[-1], edge_last)
+    del fresh
     # Krylov kernels (row-entry stores of the two-kernel iteration, perimeter-row runs, vector kernels) with 64-bit offsets
     out = []
     for eager in (True, False):
