@@ -9,7 +9,10 @@ nb, n = int(sys.argv[1]) if len(sys.argv) > 1 else 8, int(sys.argv[2]) if len(sy
 mesh = configs.strip(nb, n, n)
 for single in (False, True):
     with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax, single_sweep=single)) as sm:
-        sm.iterate(20)
+        t_settle = time.perf_counter()
+        while time.perf_counter() - t_settle < 0.25:   # settled clocks (tools/dev/ramp_probe.py)
+            sm.iterate(120)
+            torch.cuda.synchronize()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         st = sm.iterate(200)

@@ -8,6 +8,9 @@ from turbomesh_amd.smoothing import smooth, solver
 nsl, n = int(sys.argv[1]) if len(sys.argv) > 1 else 8, int(sys.argv[2]) if len(sys.argv) > 2 else 2048
 mesh = configs.slices(nsl, n)
 with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.relax)) as sm:
-    sm.iterate(20)
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < 0.25:   # settled clocks (tools/dev/ramp_probe.py)
+        sm.iterate(120)
+        torch.cuda.synchronize()
     torch.cuda.synchronize(); t0 = time.perf_counter(); sm.iterate(200); torch.cuda.synchronize(); dt = time.perf_counter() - t0
 print(f"{nsl} independent slices of {n}^2 on one GPU: {dt / 200 * 1e6:.1f} us per sweep of all slices, {nsl * n * n * 200 / dt:.3e} nodes/s")

@@ -36,14 +36,16 @@ class NativeNullHooks:
 
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
-steps = int(sys.argv[2]) if len(sys.argv) > 2 else 200   # (3000: settled clocks, see tools/dev/ramp_probe.py)
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 600   # timed behind ~0.25 s of untimed sweeps (settled clocks, see tools/dev/ramp_probe.py)
 torch.cuda.set_device(0)
 for world, cls in ((2, NullHooks), (3, NullHooks), (2, NativeNullHooks), (3, NativeNullHooks)):
     rank = 1 if world == 3 else 0      # world 3, rank 1: neighbours on both sides
     mesh = tmd.strip_for_rank(world, rank, n, n)
     h = cls(mesh, owner=list(range(world)), rank=rank, world=world, option=solver.Option.hip(inner=solver.Inner.relax))
-    h.iterate(20 if steps <= 400 else steps // 2)
-    torch.cuda.synchronize()
+    t_settle = time.perf_counter()
+    while time.perf_counter() - t_settle < 0.25:
+        h.iterate(120)
+        torch.cuda.synchronize()
     t0 = time.perf_counter()
     h.iterate(steps)
     torch.cuda.synchronize()

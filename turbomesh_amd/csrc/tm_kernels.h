@@ -122,6 +122,8 @@ void tune_fuse_rows(int rows);
 // ---- K2x3: THREE fused sweeps per pass of blocks whose perimeter rows are all `fixed` (in -> out; `mid`, `border`, `dyn` unused)
 bool relax3_supported(int ni, int nj);
 int relax3_rows_per_chunk(int ni, int nj);
+// ... chosen for the blocks of one launch together (n <= APPLY_BATCH_MAX; launch_relax3_blocks groups the blocks in this order)
+void relax3_rows_for_launch(const int* ni, const int* nj, int n, int* rows, bool beside_chain);
 int relax3_block_nwg(int ni, int nj, int rows_per_chunk);
 hipError_t launch_relax3_blocks(const Relax2Block* blocks, const int* rows_per_chunk, int n, int dot, hipStream_t stream);
 

@@ -1051,24 +1051,46 @@ __global__ __launch_bounds__(256) void k_relax3_batch(Relax2Batch B) {
     relax3_tile<DOT, U, NT, W1>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], static_cast<int>(blockIdx.x) - B.start[k]);
 }
 static int g_fuse3_rows = 0;   // experiments (TM_FUSE3_ROWS)
-int relax3_rows_per_chunk(int ni, int nj) {
+// Rows per chunk of K2x3 for the blocks of ONE launch (launch_relax3_blocks batches APPLY_BATCH_MAX blocks).
+// The pass is bound by fp64 issue under the power cap, not by bandwidth, so the rows a chunk recomputes for its neighbours
+// ((3 RI + 6) / 3 RI of the arithmetic) count: tall chunks, as long as the LAUNCH -- all its blocks together -- still puts ~0.6 x
+// 3 workgroups on every CU.  Measured (tools/dev/steady_time.py, us per sweep, two or three boxes each): the height should be
+// 2 (mod 12) -- RI + 4 steps are then whole groups of three, and chunk starts 2 x odd rows apart spread over the memory
+// channels (4096^2: 38 / 50 rows 37.4 / 36.9-38.2 against 36: 39.5, 44: 37.9-39.7, 56: 41.0, 32 at 2048^2: 11.5; odd heights
+// 35 / 39: 40.7 / 41.7).  2048^2: 38 rows 10.25, 26: 10.4 (21 rows, the earlier rule: 11.9); 1448^2: 14 rows 6.7; 1024^2: 8 rows 4.33, 14: 4.67.
+void relax3_rows_for_launch(const int* ni, const int* nj, int n, int* rows, bool beside_chain) {
     static const int forced = [] { const char* e = std::getenv("TM_FUSE3_ROWS"); return e ? std::atoi(e) : 0; }();
-    const int interior = ni - 2;
-    if (forced > 0 || g_fuse3_rows > 0) return std::max(1, std::min(forced > 0 ? forced : g_fuse3_rows, interior));
-    // The pass is bound by fp64 issue under the power cap, not by bandwidth, so the rows a chunk recomputes for its neighbours
-    // ((3 RI + 6) / 3 RI of the arithmetic) count: tall chunks, as long as the launch still fills the device a little more than
-    // once (3 workgroups per CU at 134 registers).  Steady state, us per sweep (tools/dev/steady_time.py): 4096^2 18 rows 46.8,
-    // 24: 44.9, 36 .. 72: 43.5, 96: 45.9; 2048^2 12: 13.9, 18 .. 24: 13.35, 36: 14.0; 1024^2 12: 4.9, 24: 5.3, 36: 7.1.
+    if (forced > 0 || g_fuse3_rows > 0) {
+        for (int k = 0; k < n; ++k) rows[k] = std::max(1, std::min(forced > 0 ? forced : g_fuse3_rows, ni[k] - 2));
+        return;
+    }
     static int slots = 0;
     if (slots == 0) {
         int dev = 0, cus = 0;
         if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) cus = 256;
         slots = 3 * cus;
     }
-    const int nstrips = (nj - 1 + R3_W - 1) / R3_W, nSG = (nstrips + 3) / 4;
-    int RI = 36;
-    while (RI > 12 && static_cast<long>(nSG) * ((interior + RI - 1) / RI) * 10 < static_cast<long>(slots) * 11) RI -= 3;
-    return std::max(1, std::min(RI, interior));
+    // (50 rows: a lone 4096^2 block 36.6 against 37.1 with 38, but 8 x 2048^2 in one launch 75.1 against 73.2-75.3: not offered.)
+    // Beside the perimeter-row chain of coupled blocks (relax_triples_coupled) the chain's short kernels queue for the wave slots
+    // this pass gives back, once per workgroup lifetime: shorter chunks there (a 2048^2 rank: 38 rows 13.6-13.9, 21-26 rows 13.1).
+    static const int heights[] = {38, 26, 14, 8};
+    const long need = static_cast<long>(slots) * (beside_chain ? 9 : 6);
+    int RI = 8;
+    for (const int h : heights) {
+        long total = 0;
+        for (int k = 0; k < n; ++k) {
+            const int nstrips = (nj[k] - 1 + R3_W - 1) / R3_W, nSG = (nstrips + 3) / 4, interior = ni[k] - 2, r = std::max(1, std::min(h, interior));
+            total += static_cast<long>(nSG) * ((interior + r - 1) / r);
+        }
+        RI = h;
+        if (total * 10 >= need) break;
+    }
+    for (int k = 0; k < n; ++k) rows[k] = std::max(1, std::min(RI, ni[k] - 2));
+}
+int relax3_rows_per_chunk(int ni, int nj) {
+    int r = 0;
+    relax3_rows_for_launch(&ni, &nj, 1, &r, false);
+    return r;
 }
 bool relax3_supported(int ni, int nj) { return ni >= 7 && nj >= 7 && nj <= (1 << 20); }
 int relax3_block_nwg(int ni, int nj, int RI) {
@@ -1107,7 +1129,8 @@ hipError_t launch_relax3_blocks(const Relax2Block* blocks, const int* rows_per_c
             else hipLaunchKernelGGL((KERNEL<DOT_NONE, R3_U, 1, false>), grid, block, 0, st, __VA_ARGS__);                    \
         }                                                                                                                    \
     } while (0)
-        if (B.n == 1) TM_R3(k_relax3, B.b[0], B.RI[0], B.nSG[0], B.nRC[0]);
+        static const bool force_batch = [] { const char* e = std::getenv("TM_R3_FORCE_BATCH"); return e && std::atoi(e) != 0; }();
+        if (B.n == 1 && !force_batch) TM_R3(k_relax3, B.b[0], B.RI[0], B.nSG[0], B.nRC[0]);
         else TM_R3(k_relax3_batch, B);
 #undef TM_R3
         const hipError_t rc = hipGetLastError();

@@ -526,12 +526,13 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         poff3.clear();
         rows3.clear();
         int off3 = 0;
-        for (int64_t b : lp.owned_blocks) {
+        rows3 = relax3_rows_of_owned_blocks();
+        for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
+            const int64_t b = lp.owned_blocks[k];
             const int bi = static_cast<int>(topo.ni[b]), bj = static_cast<int>(topo.nj[b]);
             if (!relax3_supported(bi, bj)) fuse_triples = false;
             poff3.push_back(off3);
-            rows3.push_back(relax3_rows_per_chunk(bi, bj));
-            off3 += relax3_block_nwg(bi, bj, rows3.back());
+            off3 += relax3_block_nwg(bi, bj, rows3[k]);
         }
         nwg_apply3 = off3;
     }
@@ -539,11 +540,12 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         poff3.clear();
         rows3.clear();
         int off3 = 0;
-        for (int64_t b : lp.owned_blocks) {
+        rows3 = relax3_rows_of_owned_blocks();
+        for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
+            const int64_t b = lp.owned_blocks[k];
             const int bi = static_cast<int>(topo.ni[b]), bj = static_cast<int>(topo.nj[b]);
             poff3.push_back(off3);
-            rows3.push_back(relax3_rows_per_chunk(bi, bj));
-            off3 += relax3_block_nwg(bi, bj, rows3.back());
+            off3 += relax3_block_nwg(bi, bj, rows3[k]);
         }
         nwg_apply3 = off3;
     }
@@ -1146,6 +1148,20 @@ void Smoother::relax2_launch(int subset, bool counts, int dot, hipStream_t on, c
     }
     const size_t lds = (subset == R2_INSIDE) ? inside_lds : 0;
     profiled([&]() { HIPCHK(launch_relax2_blocks(blocks.data(), rows2.data(), static_cast<int>(blocks.size()), dot, subset, on, lds, wait)); }, counts, on);
+}
+
+// Rows per chunk of K2x3, chosen per launch: launch_relax3_blocks takes the owned blocks in groups of APPLY_BATCH_MAX
+std::vector<int> Smoother::relax3_rows_of_owned_blocks() const {
+    std::vector<int> rows(lp.owned_blocks.size(), 1), bi, bj;
+    for (int64_t b : lp.owned_blocks) {
+        bi.push_back(static_cast<int>(topo.ni[b]));
+        bj.push_back(static_cast<int>(topo.nj[b]));
+    }
+    for (size_t first = 0; first < rows.size(); first += APPLY_BATCH_MAX) {
+        const int n = static_cast<int>(std::min<size_t>(APPLY_BATCH_MAX, rows.size() - first));
+        relax3_rows_for_launch(bi.data() + first, bj.data() + first, n, rows.data() + first, triples_coupled);
+    }
+    return rows;
 }
 
 // Three sweeps in one pass (K2x3, all perimeter rows fixed): X^(k+3) = S(S(S(X^k))), bit-identical to three single sweeps

@@ -193,6 +193,7 @@ struct Smoother {
     int picard_bicgstab(tm_stats& st);
     void relax_sweeps(uint64_t n, tm_stats& st);
     void relax_pair(bool want_partials);
+    std::vector<int> relax3_rows_of_owned_blocks() const;
     void relax_triple(bool want_partials);
     void relax_triples_coupled(uint64_t ntriples, bool want_partials_last);
     void profiled(const std::function<void()>& launch, bool counts = true, hipStream_t on = nullptr);
