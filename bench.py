@@ -9,9 +9,9 @@ in TM_INNER_RELAX mode, run through the C-ABI handle with the coordinates reside
 
   --config 2 (default)  N = 1: BASELINE configs[1] -- single synthetic 4096 x 4096 block, TFI
                         seeded on the GPU.  N > 1: weak scaling -- a strip of N such blocks stacked in i, one per GPU,
-                        coupled by interface rows exchanged point-to-point (RCCL over xGMI) between sweeps.  (A lone block
-                        with fixed walls runs three sweeps per kernel pass, coupled blocks two: the N = 1 value is not the
-                        per-GPU ceiling of the N > 1 runs -- 39.5 against 53-57 us per sweep -- see DESIGN.md section 6.)
+                        coupled by interface rows exchanged point-to-point (RCCL over xGMI), once per three sweeps.  (A lone
+                        block with fixed walls needs no perimeter-row passes beside its interior pass: the N = 1 value is not quite
+                        the per-GPU ceiling of the N > 1 runs -- 37 against 40 us per sweep -- see DESIGN.md section 6.)
   --config 4            BASELINE configs[3], STRONG scaling: 8 coupled blocks of 2048^2, 8/N blocks per GPU.
   --config 5            BASELINE configs[4]: independent 2048^2 slices, 8 per GPU ("replicas only": no communication).
 

@@ -487,6 +487,11 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
             if (total <= 512) apply_rows = r;
         }
     }
+    // a relax handle launches K2 for single sweeps only (one per pass: TM_OPT_SINGLE_SWEEP, the odd sweep behind pairs / triples): that
+    // pass is bandwidth-bound and prefers chunks of ONE six-row load group -- 4096^2: 90.8 against 96.8 us with 18 rows (0.74 against
+    // 0.69 of the HBM peak), 2048^2 28.1 / 28.6, 1024^2 8.1 / 8.6 (tools/dev/steady_time.py, STEADY_SINGLE=1); the Krylov kernels,
+    // with their seven streams, keep 18 (853 us per iteration against 874-990 for 12 / 6 / 30 / 42 rows)
+    if (!apply_rows && opt.inner == TM_INNER_RELAX) apply_rows = 6;
     if (const char* e = std::getenv("TM_APPLY_ROWS")) apply_rows = std::max(0, std::atoi(e));
     poff.clear();
     int off = 0;
