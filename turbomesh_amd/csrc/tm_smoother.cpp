@@ -1241,17 +1241,19 @@ void Smoother::relax_triples_coupled(uint64_t ntriples, bool want_partials_last)
             a.nborder = 0;
             a.partials = partials + static_cast<size_t>(poff3[k]) * MAX_PARTIALS;
         }
-        // handle's stream: K2x3 of triple q needs the chain of triple q-1 (its level 3 wrote rows of X)
+        // handle's stream: K2x3 of triple q needs the chain of triple q-1 (its level 3 wrote rows of X).  With counters, ONE one-wave
+        // kernel per queue and triple does both jobs: starting behind K2x3 of triple q-1 it announces that pass (inside_done = q), then
+        // waits for the chain of triple q-1 (chain_done >= q); its twin on the chain's queue announces the chain and waits for the pass.
+        // Both announce before they wait, so neither can hold the other up.
         if (q > 0) {
-            if (use_flags) HIPCHK(launch_queue_wait(chain_done, static_cast<uint32_t>(q), sync_err, stream));
+            if (use_flags) HIPCHK(launch_queue_signal_wait(inside_done, chain_done, static_cast<uint32_t>(q), sync_err, stream));
             else HIPCHK(hipStreamWaitEvent(stream, ev_to_main, 0));
         }
         profiled([&]() { HIPCHK(launch_relax3_blocks(blocks.data(), rows3.data(), static_cast<int>(blocks.size()), dot, stream)); }, true, stream);
-        if (use_flags) HIPCHK(launch_queue_signal(inside_done, stream));
-        else HIPCHK(hipEventRecord(ev_inside[q & 1], stream));
+        if (!use_flags) HIPCHK(hipEventRecord(ev_inside[q & 1], stream));
         // chain: the levels of triple q read X: K2x3 of triple q-1 must be complete (its own level 3 precedes them in this queue)
         if (q > 0) {
-            if (use_flags) HIPCHK(launch_queue_wait(inside_done, static_cast<uint32_t>(q), sync_err, side));
+            if (use_flags) HIPCHK(launch_queue_signal_wait(chain_done, inside_done, static_cast<uint32_t>(q), sync_err, side));
             else HIPCHK(hipStreamWaitEvent(side, ev_inside[(q - 1) & 1], 0));
         }
         exchange(X, side);                 // several ranks: X^k of the depth-3 ghost set, once per triple (a no-op otherwise)
@@ -1259,10 +1261,7 @@ void Smoother::relax_triples_coupled(uint64_t ntriples, bool want_partials_last)
         HIPCHK(launch_edge_rows(edge_L[0], X, X, PQ, nullptr, M, opt.omega, MODE_RELAX, DOT_NONE, partials, side));
         HIPCHK(launch_edge_rows(edge_L[1], M, M, PQ, nullptr, M2, opt.omega, MODE_RELAX, DOT_NONE, partials, side));
         HIPCHK(launch_edge_rows(edge_L[2], M2, M2, PQ, nullptr, U, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(nwg_apply3) * MAX_PARTIALS, side));
-        if (q + 1 < ntriples) {
-            if (use_flags) HIPCHK(launch_queue_signal(chain_done, side));
-            else HIPCHK(hipEventRecord(ev_to_main, side));
-        }
+        if (q + 1 < ntriples && !use_flags) HIPCHK(hipEventRecord(ev_to_main, side));
         std::swap(X, U);
     }
     fence(side, stream, ev_to_main);   // the handle's stream continues behind the whole chain
