@@ -978,7 +978,8 @@ __device__ __forceinline__ void relax3_strip(const Relax2Block& a, const Relax2T
     }
     // step s takes row r = i0 - 1 + s of the input, forms s1[r-1], s2[r-2], s3[r-3] and stores row r-3; s3 is live from s = 4 on
     const int nsteps = nrows + 4;
-    auto group = [&](const int tb) {
+    // (phase 0: the first group, 1: the second, 2: every later one -- a literal at each call, so the tests below fold away)
+    auto group = [&](const int tb, const int phase) {
 #pragma unroll
         for (int u = 0; u < U; ++u) pn[u] = load_in(t.i0 - 1 + tb + U + u);
 #pragma unroll
@@ -990,11 +991,19 @@ __device__ __forceinline__ void relax3_strip(const Relax2Block& a, const Relax2T
             double2 s1 = relax_row<W1>(A[A0], A[A1], A[A2], a.omega, d);          // row r-1
             if (!INSIDE && (perim_col || r - 1 <= 0 || r - 1 >= ni - 1)) s1 = A[A1].c;   // fixed: the input's own value
             S1[A2] = make_row(s1);
-            double2 s2 = relax_row<W1>(S1[A0], S1[A1], S1[A2], a.omega, d);       // row r-2
-            if (!INSIDE && (perim_col || r - 2 <= 0 || r - 2 >= ni - 1)) s2 = S1[A1].c;
-            S2[A2] = make_row(s2);
+            // the window fills from the top: the second level has its three rows from step 2 on, the third from step 4 on.  The rows
+            // they would form before that are never used (and, from windows still holding zeros, would take the slow branch of
+            // the reciprocal): skipped -- 6 of the 3 (RI + 4) evaluations of a chunk.
+            const bool do2 = phase > 0 || u >= 2, do3 = phase > 1 || (phase == 1 && u >= 1);
+            double2 s2 = zero;
+            if (do2) {
+                s2 = relax_row<W1>(S1[A0], S1[A1], S1[A2], a.omega, d);       // row r-2
+                if (!INSIDE && (perim_col || r - 2 <= 0 || r - 2 >= ni - 1)) s2 = S1[A1].c;
+            }
+            if (do2) S2[A2] = make_row(s2);   // (else: the slot keeps the zeros it was filled with)
             double2 d3 = zero;
-            const double2 o = relax_row<W1>(S2[A0], S2[A1], S2[A2], a.omega, d3);   // row r-3
+            double2 o = zero;
+            if (do3) o = relax_row<W1>(S2[A0], S2[A1], S2[A2], a.omega, d3);   // row r-3
             const int i = r - 3;
             const bool row_live = (i >= t.i0) && (i < t.i1) && (INSIDE || !(((a.dyn & 1) && i <= 2) || ((a.dyn & 2) && i >= ni - 3)));   // wave-uniform
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(v4i32, o), out_rsrc,
@@ -1008,8 +1017,10 @@ __device__ __forceinline__ void relax3_strip(const Relax2Block& a, const Relax2T
 #pragma unroll
         for (int u = 0; u < U; ++u) pc[u] = pn[u];
     };
-    group(0);
-    for (int tb = U; tb < nsteps; tb += U) group(tb);
+    static_assert(U == 3, "the phases below assume three steps per group");
+    group(0, 0);
+    group(U, 1);   // (nsteps >= 5)
+    for (int tb = 2 * U; tb < nsteps; tb += U) group(tb, 2);
 }
 
 template <int DOT, int U, int NT, bool W1>
