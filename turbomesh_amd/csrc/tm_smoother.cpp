@@ -1244,7 +1244,10 @@ void Smoother::relax_triples_coupled(uint64_t ntriples, bool want_partials_last)
         // handle's stream: K2x3 of triple q needs the chain of triple q-1 (its level 3 wrote rows of X).  With counters, ONE one-wave
         // kernel per queue and triple does both jobs: starting behind K2x3 of triple q-1 it announces that pass (inside_done = q), then
         // waits for the chain of triple q-1 (chain_done >= q); its twin on the chain's queue announces the chain and waits for the pass.
-        // Both announce before they wait, so neither can hold the other up.
+        // Both announce before they wait, so neither can hold the other up -- PROVIDED the two streams sit on different hardware queues
+        // (the chain's stream has the highest priority, the handle's is the caller's: distinct queue pools in the runtime); if they
+        // ever shared one in-order queue the second could not start, the first would run into its limit, and the handle reports
+        // TM_E_HIP (bench.py then re-creates every rank's handle with TM_PAIR_SYNC=events).
         if (q > 0) {
             if (use_flags) HIPCHK(launch_queue_signal_wait(inside_done, chain_done, static_cast<uint32_t>(q), sync_err, stream));
             else HIPCHK(hipStreamWaitEvent(stream, ev_to_main, 0));
