@@ -218,6 +218,29 @@ def solve_to_converged(n, smooth, solver, configs, tol=1e-10, inexact=False):
                        else "hip/mg_bicgstab, default options (inner rtol 7.5e-9 / nodes: every Picard iterate the exact-solve one)")}
 
 
+KRYLOV_BYTES_PER_NODE = 256.0   # one two-kernel BiCGStab iteration: 176 + 80 B per node
+
+
+def krylov_iteration(n, smooth, solver, configs, iters=100):
+    """The route that actually converges, priced against the same roofline: time per BiCGStab iteration (two kernels, k_apply_vk<VK_R> +
+    k_apply_vk<VK_S>, both coordinate components together) of one Picard solve on the perturbed n x n block, capped at `iters` inner
+    iterations with no convergence poll in between.  Second of two identical solves (the first loads the kernels)."""
+    import torch
+
+    mesh = configs.single_block(n, n, perturb=0.25)
+    us = None
+    for _ in range(2):
+        with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.bicgstab, rtol=1e-30, max_inner=iters, check_every=iters)) as sm:
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            st = sm.iterate(1)
+            torch.cuda.synchronize()
+            us = (time.perf_counter() - t0) * 1e6 / max(1, st["inner_iterations"])
+    gbps = KRYLOV_BYTES_PER_NODE * n * n / (us * 1e-6) / 1e9
+    return {"iteration_us": us, "inner_iterations": st["inner_iterations"], "bytes_per_node": KRYLOV_BYTES_PER_NODE, "achieved_GBps": gbps,
+            "frac": gbps / HBM_PEAK_GBPS, "what": "hip/bicgstab, two fused kernels per iteration, wall time of one capped Picard solve / iterations (set-up kernels included)"}
+
+
 def self_launch(args):
     """--gpus N without a launcher: start N fresh ranks as a CHILD process (this process has not touched the GPU and never
     will) and relay rank 0's JSON line."""
@@ -336,7 +359,9 @@ def main():
         owner = [b // bpr for b in range(nblocks_total)]
         owned = [b for b in range(nblocks_total) if owner[b] == rank]
         transport = "torch.distributed p2p (Python hooks)"
-        if backend == "nccl" and args.transport == "rccl":
+        # (TM_RCCL_LIB: the path tm_rccl_* dlopens instead of torch's librccl.  With torch.distributed on gloo -- several ranks on ONE GPU,
+        # which real RCCL refuses -- it is what lets the library's own transport run at all: tests/loopback_rccl, test infrastructure.)
+        if args.transport == "rccl" and (backend == "nccl" or os.environ.get("TM_RCCL_LIB")):
             # The library's own RCCL transport.  Every rank first checks what it can check ALONE (librccl loads, its symbols
             # resolve, a unique id can be made) and the ranks vote BEFORE any collective call: a rank that failed locally
             # would otherwise leave the others blocked inside ncclCommInitRank.  Then the transport is checked once against
@@ -346,30 +371,48 @@ def main():
                 tmd.RcclHooks.precheck()
             except Exception as e:   # noqa: BLE001
                 ok, why = 0, repr(e)
-            flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+            flag_dev = "cuda" if backend == "nccl" else "cpu"
+            flag = torch.tensor([ok], dtype=torch.int32, device=flag_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
+                # the check runs the schedule of the timed region: with TM_TRIPLES_MIN_NODES=1 (read at every plan build) the small strip
+                # takes the depth-3 halo and the coupled sweep triples of the 2048^2 / 4096^2 blocks, 9 sweeps = three triples; then 4
+                # more through the pair schedule (depth-2 exchange lists)
+                saved_min = os.environ.get("TM_TRIPLES_MIN_NODES")
                 try:
                     # one handle at a time: a process with a single multi-rank handle orders its two queues with counters in
                     # device memory (the schedule of the timed run); two live handles would both fall back to events
                     small = [tmd.strip_for_rank(world, rank, 192, 256, blocks_per_rank=bpr) for _ in range(2)]
-                    h_a = tmd.RcclHooks(small[0], owner=owner, rank=rank, world=world, option=relax_opt)
-                    h_a.iterate(6)
-                    h_a.smoother.download()
-                    h_a.close()
-                    h_b = tmd.TorchHooks(small[1], owner=owner, rank=rank, world=world, option=relax_opt)
-                    h_b.iterate(6)
-                    h_b.smoother.download()
-                    h_b.smoother.close()
-                    ok = int(all(np.array_equal(small[0].blocks[b].points.data, small[1].blocks[b].points.data) for b in owned))
+                    ok = 1
+                    for min_nodes, sweeps in (("1", 9), (None, 4)):
+                        if min_nodes is None:
+                            os.environ.pop("TM_TRIPLES_MIN_NODES", None)
+                            if saved_min is not None:
+                                os.environ["TM_TRIPLES_MIN_NODES"] = saved_min
+                        else:
+                            os.environ["TM_TRIPLES_MIN_NODES"] = min_nodes
+                        small = [tmd.strip_for_rank(world, rank, 192, 256, blocks_per_rank=bpr) for _ in range(2)]
+                        h_a = tmd.RcclHooks(small[0], owner=owner, rank=rank, world=world, option=relax_opt)
+                        h_a.iterate(sweeps)
+                        h_a.smoother.download()
+                        h_a.close()
+                        h_b = tmd.TorchHooks(small[1], owner=owner, rank=rank, world=world, option=relax_opt)
+                        h_b.iterate(sweeps)
+                        h_b.smoother.download()
+                        h_b.smoother.close()
+                        ok = ok and int(all(np.array_equal(small[0].blocks[b].points.data, small[1].blocks[b].points.data) for b in owned))
                     why = "" if ok else "coordinates differ from the torch.distributed transport"
                 except Exception as e:   # noqa: BLE001 -- any failure means: use the other transport
                     ok, why = 0, repr(e)
-                flag = torch.tensor([ok], dtype=torch.int32, device="cuda")
+                finally:
+                    os.environ.pop("TM_TRIPLES_MIN_NODES", None)
+                    if saved_min is not None:
+                        os.environ["TM_TRIPLES_MIN_NODES"] = saved_min
+                flag = torch.tensor([ok], dtype=torch.int32, device=flag_dev)
                 dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             use_native = int(flag.item()) == 1
             if use_native:
-                transport = "RCCL p2p issued by libtm_hip (tm_rccl_*)"
+                transport = "RCCL p2p issued by libtm_hip (tm_rccl_*)" + (f" through $TM_RCCL_LIB = {os.path.basename(os.environ['TM_RCCL_LIB'])}" if os.environ.get("TM_RCCL_LIB") else "")
             else:
                 print(f"[bench] rank {rank}: native RCCL transport not used ({why or 'another rank declined'})", file=sys.stderr)
         else:
@@ -417,8 +460,18 @@ def main():
     est_us = 55.0 * nodes_rank_est / (4096.0 * 4096.0)
     settle_steps = 0 if args.settle_ms <= 0 else max(60, min(60000, int(args.settle_ms * 1e3 / max(est_us, 0.5)) // 6 * 6))
     ok = 1
+    cold_dt = None
+    pre_steps = (args.warmup + args.steps + settle_steps) if settle_steps else 0   # untimed sweeps in front of the W warm-up steps
     try:
         if settle_steps:
+            # the figure a W + K run WITHOUT the settling phase reads (kernels loaded by the W steps, clocks not yet settled):
+            # reported as config.cold_ms_per_step beside ms_per_step, never used for `value`
+            sm.iterate(args.warmup)
+            torch.cuda.synchronize()
+            tc = time.perf_counter()
+            sm.iterate(args.steps)
+            torch.cuda.synchronize()
+            cold_dt = time.perf_counter() - tc
             sm.iterate(settle_steps)
         sm.iterate(args.warmup)
         torch.cuda.synchronize()
@@ -441,6 +494,7 @@ def main():
         hooks_obj = make_coupled_handle()
         sm = hooks_obj.smoother
         sm.iterate(settle_steps + args.warmup)
+        pre_steps, cold_dt = settle_steps, None
         pair_sync = "events (fallback: a device-side wait of the counter-ordered schedule timed out during warm-up)"
     sm.profile(max(1, args.profile_every))
     barrier()
@@ -463,14 +517,14 @@ def main():
         if rank == 0:
             whole = configs.strip(nblocks_total, n, n)
             with smooth.Smoother(whole, relax_opt) as ref:
-                if settle_steps:
-                    ref.iterate(settle_steps)
+                if pre_steps:
+                    ref.iterate(pre_steps)
                 ref.iterate(args.warmup)
                 ref.iterate(args.steps)
                 ref.download()
             got = np.concatenate([p.cpu().numpy() for p in parts])
             verified = all(np.array_equal(got[b], whole.blocks[b].points.data) for b in range(nblocks_total))
-            print(f"[bench] --verify: {world} ranks vs one handle after {settle_steps}+{args.warmup}+{args.steps} sweeps: {'bit-identical' if verified else 'MISMATCH'}", file=sys.stderr)
+            print(f"[bench] --verify: {world} ranks vs one handle after {pre_steps}+{args.warmup}+{args.steps} sweeps: {'bit-identical' if verified else 'MISMATCH'}", file=sys.stderr)
 
     if dist is not None:
         tt = torch.tensor([dt], dtype=torch.float64, device="cuda" if dist.get_backend() == "nccl" else "cpu")
@@ -553,15 +607,21 @@ def main():
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "nodes_total": nodes_total, "nodes_per_gpu": nodes_rank,
                        "solver": "hip/relax (fused Jacobi elliptic sweep" + (f", {spl} sweeps per kernel pass)" if fused else ")"), "omega": 1.0,
+                       "settle_steps": settle_steps, "cold_ms_per_step": (cold_dt / args.steps * 1e3 if cold_dt else None),
+                       "cold_value": (nodes_rank * args.steps / cold_dt if cold_dt and dist is None else None),
                        "settle": {"steps": settle_steps, "why": "untimed sweeps of the same workload before the W warm-up steps: the pass runs at the board power cap and "
                                   "the clock needs ~50 ms of load to settle (tools/dev/ramp_probe.py); --settle-ms 0 turns it off"},
                        "residual_last": st["last_residual"], **({"verified_against_single_handle": verified} if verified is not None else {}),
-                       **({"pair_sync": pair_sync} if pair_sync else {}),
+                       **({"pair_sync": pair_sync, "queue_ordering": sm.queue_ordering()[1]} if pair_sync else {}),
                        "sweep_equiv_GBps_whole_job": BYTES_PER_NODE * value / 1e9},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBPS,
                          "traffic": traffic, "traffic_source": traffic_src,
                          "valu_issue": valu,
+                         "valu_issue_frac": (valu["frac"] if valu else None),
                          "single_sweep_reference": single_ref,
+                         "single_sweep_us": (single_ref["avg_launch_us"] if single_ref else None),
+                         "single_sweep_frac": (single_ref["frac"] if single_ref else None),
+                         "stream_copy_GBps": (stream["copy"] if stream else None), "stream_triad_GBps": (stream["triad"] if stream else None),
                          "stream_ceiling_GBps": (max(stream.values()) if stream else None),
                          "frac_of_stream": (achieved / max(stream.values()) if stream else None),
                          "stream": ({**stream, "what": f"tm_stream_probe in this run: copy / triad of {16 * nodes_rank / 2**20:.0f} MiB per array, non-temporal 16 B/lane, 20 launches each"}
@@ -571,7 +631,9 @@ def main():
                                         "more sweeps per pass trade HBM bytes for nothing but the arithmetic the sweeps need anyway, so `frac` falls while nodes/s rise"
                                         if fused else "HBM"),
                          "sweeps_per_launch": sweeps_per_launch, "bytes_per_launch": bytes_per_launch,
-                         "bytes_model": "32 B per owned node per LAUNCH: the field is read once and written once per pass (rank 0's blocks)",
+                         "bytes_model": ("32 B per owned node per LAUNCH: the field is read once and written once per pass (rank 0's blocks); the residual-norm "
+                                         "partial sums ride only in the LAST launch of an iterate() call (the one whose norms are read back; measured cost nil: "
+                                         "k_relax3<DOT_DELTA> 115.1 us against 115.06 without)"),
                          "sweep_equiv_GBps": BYTES_PER_NODE * nodes_rank * sweeps_per_launch / k2_avg_s / 1e9,
                          "sweep_equiv_note": ("SURVEY 8d counts 32 B per node per SWEEP; a temporally blocked pass performs several sweeps for one read + one write, "
                                               "so this figure may exceed the HBM peak -- it is not a bandwidth") if fused else "one sweep per launch: equals achieved",
@@ -593,13 +655,31 @@ def main():
             out["config"]["value_1gpu_stored"] = ref1
             out["config"]["vs_1gpu"] = (value / ref1) if ref1 else None
         if world == 1 and args.config == 2 and not args.no_solve:
-            out["config"]["solve_to_1e-8"] = solve_to_tolerance(n, smooth, solver, configs)
-            out["config"]["solve_to_converged"] = solve_to_converged(n, smooth, solver, configs)
-            out["config"]["solve_to_converged_inexact_picard"] = solve_to_converged(n, smooth, solver, configs, inexact=True)
+            c = out["config"]
+            c["solve_to_1e-8"] = solve_to_tolerance(n, smooth, solver, configs)
+            c["solve_to_converged"] = solve_to_converged(n, smooth, solver, configs)
+            c["solve_to_converged_inexact_picard"] = solve_to_converged(n, smooth, solver, configs, inexact=True)
+            # the same figures as scalars (a reader that keeps only two levels of the line still sees them)
+            c["solve_to_1e-8_ms"] = c["solve_to_1e-8"]["seconds"] * 1e3
+            c["solve_to_converged_ms"] = c["solve_to_converged"]["seconds"] * 1e3
+            c["solve_to_converged_outer"] = c["solve_to_converged"]["outer_iterations"]
+            c["solve_to_converged_inner"] = c["solve_to_converged"]["inner_iterations"]
+            c["solve_to_converged_inexact_ms"] = c["solve_to_converged_inexact_picard"]["seconds"] * 1e3
+            try:
+                kr = krylov_iteration(n, smooth, solver, configs)
+                out["roofline"]["krylov"] = kr
+                out["roofline"]["krylov_iter_us"] = kr["iteration_us"]
+                out["roofline"]["krylov_frac"] = kr["frac"]
+            except Exception as e:   # noqa: BLE001 -- a diagnostic must not cost the line
+                print(f"[bench] Krylov iteration probe failed: {e}", file=sys.stderr)
         if not args.no_cpu_baseline and world == 1 and args.config == 2:
             cb = cpu_baseline(n)
             if not args.no_solve and "t106_json_as_written" in cb:
                 cb["t106_json_as_written"]["gpu_same_job"] = t106_gpu(smooth, solver, wcf)
+                cb["t106_cpu_seconds"] = cb["t106_json_as_written"]["cpu_seconds"]
+                cb["t106_gpu_seconds"] = cb["t106_json_as_written"]["gpu_same_job"]["gpu_seconds"]
+            cb["mirror_sweep_nodes_per_s_1_thread"] = cb["mirror_sweep"]["value"]
+            cb["mirror_sweep_nodes_per_s_all_threads"] = cb["mirror_sweep"]["all_threads"]["value"]
             out["cpu_baseline"] = cb
         elif not args.no_cpu_baseline:
             out["cpu_baseline"] = None

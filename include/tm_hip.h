@@ -16,7 +16,9 @@
  *   - every function returns int: 0 = ok, >0 = warning status, <0 = tm_error; the message is
  *     available from tm_last_error() (pattern: cg_get_error, reference src/core/cgns.zig:19-22);
  *     nothing aborts the process;
- *   - not re-entrant per handle; no hidden global state besides the HIP runtime.
+ *   - not re-entrant per handle; no hidden global state besides the HIP runtime;
+ *   - measurement and diagnostic entry points (event timing of the dominant kernel, the STREAM-style probe, the White math probe,
+ *     how a handle orders its two queues) are declared in tm_hip_diag.h, not here: a binding needs none of them.
  */
 #ifndef TM_HIP_H
 #define TM_HIP_H
@@ -113,10 +115,15 @@ enum {
     TM_INNER_BICGSTAB = 0,   /* Picard outer iteration (smooth.zig:104-154), each frozen-coefficient system solved by
                                 matrix-free BiCGStab on the row-equilibrated operator D^-1 A (replaces BiCGStab.zig:279-370) */
     TM_INNER_RELAX = 1,      /* every outer iteration is ONE fused Jacobi elliptic sweep X <- X + omega D^-1 (b - A(X) X)   */
-    TM_INNER_MG_BICGSTAB = 2 /* TM_INNER_BICGSTAB, right-preconditioned by one geometric-multigrid V(2,2) cycle per block
+    TM_INNER_MG_BICGSTAB = 2,/* TM_INNER_BICGSTAB, right-preconditioned by one geometric-multigrid V(2,2) cycle per block
                                 (damped Jacobi, full weighting, rediscretised Winslow operator on vertex-coarsened levels;
                                 perimeter rows keep the identity).  Same Picard iterates, far fewer inner iterations on
                                 large blocks: what makes "to 1e-8 residual at 4096^2" practical               */
+    TM_INNER_AUTO = 3        /* resolved when the handle is created, from the mesh alone (every rank of a job decides alike):
+                                TM_INNER_MG_BICGSTAB when the largest block has >= 100 000 nodes, TM_INNER_BICGSTAB below -- on the
+                                reference's example meshes (T106 / LS89: 8 blocks of 10^2..10^4 nodes) every multigrid level is a handful
+                                of launch-bound kernels and the plain solver is 7x faster in wall time; from ~300^2 nodes per block on
+                                the cycle's O(1) iteration count wins.  Same Picard iterates either way.        */
 };
 /* tm_solver_opt.flags */
 enum {
@@ -294,6 +301,8 @@ int tm_smoother_rhs(tm_smoother* s, double* rhs_xy);
 /* Row kind per global row: -1 interior, else BlockBoundaryPointKind (smooth.zig:1168-1174). */
 int tm_smoother_row_kinds(const tm_smoother* s, int32_t* kinds /* [dof] */);
 uint64_t tm_smoother_dof(const tm_smoother* s);
+/* The inner strategy the handle runs (TM_INNER_*): what TM_INNER_AUTO resolved to, else the option as given. */
+int tm_smoother_inner(const tm_smoother* s);
 /* Current control function (P,Q) per node, 2*dof doubles (wall_control_function.zig:22-54). */
 int tm_smoother_control_function(tm_smoother* s, double* pq);
 
@@ -305,13 +314,6 @@ int tm_smoother_control_function(tm_smoother* s, double* pq);
  * block from the coordinates resident in the handle; p, q may both be NULL (laplace exports zeros). */
 int tm_export_soa(const double* xy /* ni*nj*2 */, uint64_t ni, uint64_t nj, double* x_out /* ni*nj */, double* y_out /* ni*nj */);
 int tm_smoother_export_soa(tm_smoother* s, uint64_t block, double* x, double* y, double* p, double* q);
-
-/* Measurement support (bench.py roofline): with every = k > 0, every k-th launch of the dominant kernel (K2
- * `winslow_apply` / K2x2 / K2x3) is bracketed by a pair of HIP events recorded on the handle's stream (0 = off); read returns
- * the summed elapsed milliseconds of the bracketed launches, how many were bracketed and how many ran since the last
- * read (and resets all three). */
-int tm_smoother_profile(tm_smoother* s, int every);
-int tm_smoother_profile_read(tm_smoother* s, double* k2_ms_total, uint64_t* k2_launches_timed, uint64_t* k2_launches);
 
 /* ------------------------------------------------------------------ host-only planning (no GPU needed)
  * The perimeter-row table the device kernels consume, exported as CSR so it can be compared with
@@ -362,15 +364,6 @@ typedef struct tm_plan_local_info {
 } tm_plan_local_info;
 int tm_plan_local(const tm_mesh_desc* mesh, const int32_t* owner, int32_t rank, int32_t nranks, tm_plan_local_info* out);
 void tm_plan_local_free(tm_plan_local_info* info);
-
-/* Diagnostic: the STREAM-style ceiling of this GPU at a footprint of `bytes` per array (SURVEY 8d asks for it beside the 8 TB/s
- * specification): copy (b = a: 2 x bytes moved) and triad (a = b + s c: 3 x bytes), 16 B per lane, non-temporal loads and stores --
- * the access pattern of the library's vector kernels -- averaged over `iters` launches after 3 warm-up launches; GB/s = 1e9 B/s. */
-int tm_stream_probe(uint64_t bytes, int32_t iters, double* copy_GBps, double* triad_GBps);
-
-/* Diagnostic: acos(x[i]) and atan2(y[i], x[i]) exactly as the White kernels evaluate them on the device (csrc/tm_refmath.h: the
- * reference's libm algorithm, Zig std.math = musl's, wall_control_function.zig:298-308).  Host arrays in and out. */
-int tm_white_math_probe(const double* x, const double* y, uint64_t n, double* out_acos, double* out_atan2);
 
 /* ------------------------------------------------------------------ device-level entry points
  * Same kernels on caller-provided DEVICE pointers and stream, for callers that keep blocks in

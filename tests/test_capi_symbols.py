@@ -10,12 +10,26 @@ from turbomesh_amd import _capi
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _declared_functions():
-    src = open(os.path.join(ROOT, "include", "tm_hip.h")).read()
+def _declared_in(header):
+    src = open(os.path.join(ROOT, "include", header)).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     names = set(re.findall(r"\b(tm_[a-z0-9_]+)\s*\(", src))
     names -= {"tm_comm_hooks"}
     return sorted(names)
+
+
+DIAGNOSTIC = ["tm_smoother_profile", "tm_smoother_profile_read", "tm_smoother_queue_ordering", "tm_stream_probe", "tm_white_math_probe"]
+
+
+def _declared_functions():
+    # the drop-in surface (tm_hip.h) + the measurement / diagnostic entry points (tm_hip_diag.h), both exported by the one product library
+    return sorted(set(_declared_in("tm_hip.h")) | set(_declared_in("tm_hip_diag.h")))
+
+
+def test_diagnostics_live_in_their_own_header():
+    # nothing a binding of the reference needs is a measurement helper, and no measurement helper sits in the drop-in header
+    assert _declared_in("tm_hip_diag.h") == DIAGNOSTIC
+    assert not set(DIAGNOSTIC) & set(_declared_in("tm_hip.h"))
 
 
 def test_header_symbols_exported():

@@ -147,3 +147,26 @@ def test_three_sweeps_per_pass_on_coupled_blocks(kind, monkeypatch):
         sm.iterate(3)
         sm.download()
     assert np.array_equal(mesh_flat(mesh), hist["single"][0][0])
+
+
+def test_inner_auto_is_decided_by_the_largest_block():
+    # solver.zig:18-27's option shape with one more payload value: `auto` resolves at create -- the plain solve on meshes of small blocks
+    # (the reference's examples), the multigrid-preconditioned one from 100 000 nodes per block on; explicit choices are kept
+    from turbomesh_amd import configs
+    from turbomesh_amd.smoothing import smooth, solver
+
+    auto = solver.Option.hip(inner=solver.Inner.auto)
+    for mesh, want in ((configs.single_block(221, 41), solver.Inner.bicgstab), (configs.strip(3, 40, 50), solver.Inner.bicgstab),
+                       (configs.single_block(316, 316), solver.Inner.bicgstab), (configs.single_block(317, 317), solver.Inner.mg_bicgstab),
+                       (configs.strip(2, 64, 2000), solver.Inner.mg_bicgstab)):
+        with smooth.Smoother(mesh, auto) as sm:
+            assert sm.inner == want
+    with smooth.Smoother(configs.single_block(400, 400), solver.Option.hip(inner=solver.Inner.bicgstab)) as sm:
+        assert sm.inner == solver.Inner.bicgstab
+    # and both reach the same Picard iterates (a preconditioner changes the route, not the destination)
+    a, b = configs.single_block(330, 330, perturb=0.2), configs.single_block(330, 330, perturb=0.2)
+    smooth.mesh(a, 2, auto)
+    smooth.mesh(b, 2, solver.Option.hip(inner=solver.Inner.bicgstab))
+    import numpy as np
+
+    assert float(np.sqrt(np.mean((a.blocks[0].points.data - b.blocks[0].points.data) ** 2))) <= 1e-10

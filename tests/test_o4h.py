@@ -178,6 +178,9 @@ def test_cli_runs_the_t106_input_with_the_hip_solver(tmp_path):
     r = subprocess.run([sys.executable, "-m", "turbomesh_amd", cfg, "--hip", "--iterations", "2", "--output", out], capture_output=True, text=True,
                        timeout=300, cwd=GOLD, env=env)
     assert r.returncode == 0, r.stderr
+    # --hip without a strategy = auto: on these blocks (<= 9061 nodes) that is the plain Picard + BiCGStab solve (7x faster here than the
+    # multigrid-preconditioned one); the program says which one it took
+    assert "inner strategy: bicgstab (chosen from the block sizes)" in r.stderr, r.stderr[-2000:]
     blocks = output.read_plot3d(out)
     assert [(b[0], b[1]) for b in blocks] == [(221, 41), (121, 41), (11, 41), (11, 51), (121, 41), (161, 11), (21, 91), (11, 131)]
     assert all(np.isfinite(b[2]).all() and np.isfinite(b[3]).all() for b in blocks)

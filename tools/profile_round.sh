@@ -4,12 +4,15 @@
 # kernel-trace + stats of the bench command (three sweeps per pass = the default on a block with fixed walls, two per pass, and --single-sweep), of the Krylov and multigrid paths, and the
 # two SEPARATE --pmc passes (FETCH_SIZE, WRITE_SIZE; never combined with tracing domains) that profiles/traffic.json is made from.
 set -u
-tag=${1:-r03}
+tag=${1:-r04}
 root=${GRAFT_REPO_ROOT:-$(pwd)}
 out=$root/gpurun_out/prof_$tag
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
-prof() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d "$out/$name" -o p -- "$@" > "$out/$name.out" 2> "$out/$name.err"; cp "$out/$name"/p_kernel_stats.csv "$out/${tag}_${name}_kernel_stats.csv" 2>/dev/null; }
+prof() { name=$1; shift; rocprofv3 --kernel-trace --stats --output-format csv -d "$out/$name" -o p -- "$@" > "$out/$name.out" 2> "$out/$name.err"; cp "$out/$name"/p_kernel_stats.csv "$out/${tag}_${name}_kernel_stats.csv" 2>/dev/null;
+  # the same run without the clock ramp of the cold device (launches starting within 60 ms of a kernel's first launch dropped): the file the bench line's `frac` is checked against
+  python3 "$root/tools/steady_stats.py" "$out/$name"/p_kernel_trace.csv "$out/${tag}_${name}_kernel_steady.csv" --skip-ms 60 > "$out/$name.steady.txt" 2>&1;
+  grep -h '^{' "$out/$name.out" > "$out/${tag}_${name}_line.json" 2>/dev/null; }
 prof bench4096_k2x3 python3 "$root/bench.py" --no-cpu-baseline --no-solve
 TM_FUSE_3=0 prof bench4096_k2x2 python3 "$root/bench.py" --no-cpu-baseline --no-solve
 prof bench4096_k2_single python3 "$root/bench.py" --no-cpu-baseline --no-solve --single-sweep

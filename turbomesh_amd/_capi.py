@@ -21,7 +21,7 @@ TM_E_SIZE, TM_E_TOPOLOGY, TM_E_MISMATCH, TM_E_OVERFLOW, TM_E_UNSUPPORTED, TM_E_A
 _ERR_NAMES = {-1: "InconsistentSize", -2: "Topology", -3: "Mismatch", -4: "Overflow", -5: "ExternalSolverNotEnabled", -6: "Argument",
               -7: "OutOfMemory", -8: "Hip", -9: "Comm"}
 TM_SOLVER_GMRES, TM_SOLVER_BICGSTAB, TM_SOLVER_UMFPACK, TM_SOLVER_PETSC, TM_SOLVER_HIP = 0, 1, 2, 3, 4
-TM_INNER_BICGSTAB, TM_INNER_RELAX, TM_INNER_MG_BICGSTAB = 0, 1, 2
+TM_INNER_BICGSTAB, TM_INNER_RELAX, TM_INNER_MG_BICGSTAB, TM_INNER_AUTO = 0, 1, 2, 3
 TM_CF_LAPLACE, TM_CF_WHITE = 0, 1
 
 
@@ -116,7 +116,7 @@ EXPORTS = [
     "tm_smoother_exchange_plan", "tm_smoother_apply", "tm_smoother_rhs", "tm_smoother_row_kinds", "tm_smoother_dof",
     "tm_smoother_control_function", "tm_smoother_profile", "tm_smoother_profile_read", "tm_plan_build", "tm_plan_free", "tm_plan_local", "tm_plan_local_free", "tm_dev_tfi_block", "tm_dev_relax_sweep",
     "tm_dev_relax_partials_needed", "tm_export_soa", "tm_smoother_export_soa", "tm_rccl_unique_id", "tm_rccl_comm_create", "tm_rccl_comm_destroy", "tm_rccl_hooks",
-    "tm_rccl_peer_table_build", "tm_rccl_peer_table_free", "tm_white_math_probe", "tm_stream_probe",
+    "tm_rccl_peer_table_build", "tm_rccl_peer_table_free", "tm_white_math_probe", "tm_stream_probe", "tm_smoother_queue_ordering", "tm_smoother_inner",
 ]
 
 _lib = None
@@ -185,6 +185,8 @@ def lib():
         L.tm_smoother_control_function.argtypes = [C.c_void_p, _dp]
         L.tm_smoother_profile.argtypes = [C.c_void_p, C.c_int]
         L.tm_smoother_profile_read.argtypes = [C.c_void_p, _dp, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)]
+        L.tm_smoother_queue_ordering.argtypes = [C.c_void_p]
+        L.tm_smoother_inner.argtypes = [C.c_void_p]
         L.tm_plan_build.argtypes = [C.POINTER(tm_mesh_desc), C.POINTER(tm_plan_rows)]
         L.tm_plan_free.argtypes = [C.POINTER(tm_plan_rows)]
         L.tm_plan_free.restype = None

@@ -1,4 +1,4 @@
-// extern "C" surface of libtm_hip.so (declared in include/tm_hip.h).
+// extern "C" surface of libtm_hip.so (declared in include/tm_hip.h; measurement / diagnostic entry points in include/tm_hip_diag.h).
 #include "tm_smoother.hpp"
 #include <cmath>
 #include <cstdlib>
@@ -85,46 +85,65 @@ int tm_diag_apply(const double* d_in, double* d_out, uint64_t ni, uint64_t nj, i
 #endif   // TM_DEBUG_EXPORTS
 
 // ------------------------------------------------------------------ TFI (tfi.zig:112-208)
-// diagnostic (include/tm_hip.h): what this GPU sustains on a plain copy / triad of `bytes` per array, vector-kernel access pattern
+// diagnostic (include/tm_hip_diag.h): what this GPU sustains on a plain copy / triad of `bytes` per array, vector-kernel access pattern.
+// Runs on a private non-blocking stream (the legacy null stream would synchronise with every blocking stream of the process, and a
+// multi-rank job calls this on rank 0 while the other ranks move on); stream and events are released on every path.
+namespace {
+struct ProbeStream {
+    hipStream_t s = nullptr;
+    hipEvent_t e0 = nullptr, e1 = nullptr;
+    ProbeStream() {
+        HIPCHK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+        HIPCHK(hipEventCreate(&e0));
+        HIPCHK(hipEventCreate(&e1));
+    }
+    ~ProbeStream() {
+        if (e0) (void)hipEventDestroy(e0);
+        if (e1) (void)hipEventDestroy(e1);
+        if (s) {
+            (void)hipStreamSynchronize(s);
+            (void)hipStreamDestroy(s);
+        }
+    }
+    ProbeStream(const ProbeStream&) = delete;
+    ProbeStream& operator=(const ProbeStream&) = delete;
+};
+}  // namespace
 int tm_stream_probe(uint64_t bytes, int32_t iters, double* copy_GBps, double* triad_GBps) {
     return guarded([&]() {
         if (bytes < 4096 || iters < 1 || !copy_GBps || !triad_GBps) throw TmError(TM_E_ARG, "bad argument");
         require_gfx950();
         const int64_t n = static_cast<int64_t>(bytes / sizeof(double2));
         DevBuf a(sizeof(double2) * n), b(sizeof(double2) * n), c(sizeof(double2) * n);
-        HIPCHK(hipMemset(a.p, 0, sizeof(double2) * n));
-        HIPCHK(hipMemset(b.p, 0, sizeof(double2) * n));
-        HIPCHK(hipMemset(c.p, 0, sizeof(double2) * n));
-        hipEvent_t e0, e1;
-        HIPCHK(hipEventCreate(&e0));
-        HIPCHK(hipEventCreate(&e1));
+        ProbeStream ps;
+        HIPCHK(hipMemsetAsync(a.p, 0, sizeof(double2) * n, ps.s));
+        HIPCHK(hipMemsetAsync(b.p, 0, sizeof(double2) * n, ps.s));
+        HIPCHK(hipMemsetAsync(c.p, 0, sizeof(double2) * n, ps.s));
         double out[2] = {0.0, 0.0};
         for (int kind = 0; kind < 2; ++kind) {
             // the direction alternates (a <- b, b <- a, ...), like the two fields of a relaxation sweep: a source that no launch ever writes
             // would be served from the 256 MB Infinity Cache and read as "8.5 TB/s" (tools/ubench/stream.hip)
             auto once = [&](int k) {
                 double2* v[3] = {a.as<double2>(), b.as<double2>(), c.as<double2>()};
-                if (kind == 0) return launch_stream(0, v[k & 1], v[(k & 1) ^ 1], v[2], 0.5, n, nullptr);
-                return launch_stream(1, v[k % 3], v[(k + 1) % 3], v[(k + 2) % 3], 0.5, n, nullptr);   // the three arrays rotate
+                if (kind == 0) return launch_stream(0, v[k & 1], v[(k & 1) ^ 1], v[2], 0.5, n, ps.s);
+                return launch_stream(1, v[k % 3], v[(k + 1) % 3], v[(k + 2) % 3], 0.5, n, ps.s);   // the three arrays rotate
             };
             for (int w = 0; w < 4; ++w) HIPCHK(once(w));
-            HIPCHK(hipEventRecord(e0, nullptr));
+            HIPCHK(hipEventRecord(ps.e0, ps.s));
             for (int k = 0; k < iters; ++k) HIPCHK(once(k));
-            HIPCHK(hipEventRecord(e1, nullptr));
-            HIPCHK(hipEventSynchronize(e1));
+            HIPCHK(hipEventRecord(ps.e1, ps.s));
+            HIPCHK(hipEventSynchronize(ps.e1));
             float ms = 0.f;
-            HIPCHK(hipEventElapsedTime(&ms, e0, e1));
+            HIPCHK(hipEventElapsedTime(&ms, ps.e0, ps.e1));
             out[kind] = static_cast<double>(kind == 1 ? 3 : 2) * sizeof(double2) * n * iters / (1e-3 * ms) / 1e9;
         }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
         *copy_GBps = out[0];
         *triad_GBps = out[1];
         return TM_OK;
     });
 }
 
-// diagnostic (include/tm_hip.h, tests/test_gpu_refmath.py): acos(x[i]) and atan2(y[i], x[i]) as the device's White kernels evaluate
+// diagnostic (include/tm_hip_diag.h, tests/test_gpu_refmath.py): acos(x[i]) and atan2(y[i], x[i]) as the device's White kernels evaluate
 // them (tm_refmath.h), host arrays in and out
 int tm_white_math_probe(const double* x, const double* y, uint64_t n, double* out_acos, double* out_atan2) {
     return guarded([&]() {
@@ -394,6 +413,11 @@ int tm_smoother_profile_read(tm_smoother* s, double* k2_ms_total, uint64_t* k2_l
         return TM_OK;
     });
 }
+
+int tm_smoother_inner(const tm_smoother* s) { return s ? s->impl.opt.inner : static_cast<int>(TM_E_ARG); }
+
+// how the handle orders the two queues of a pipelined pass (include/tm_hip_diag.h)
+int tm_smoother_queue_ordering(const tm_smoother* s) { return s ? s->impl.queue_ordering : static_cast<int>(TM_E_ARG); }
 
 // ------------------------------------------------------------------ seam 1 (smooth.zig:74-80)
 int tm_smooth_mesh(const tm_mesh_desc* mesh, uint64_t iterations, const tm_solver_opt* opt, const tm_control_fn* cf, tm_stats* stats) {

@@ -1,6 +1,6 @@
 // Helpers shared by the translation units that implement the extern "C" surface (tm_api.cpp, tm_rccl.cpp).
 #pragma once
-#include "../../include/tm_hip.h"
+#include "../../include/tm_hip_diag.h"
 #include "tm_smoother.hpp"
 
 #include <cmath>

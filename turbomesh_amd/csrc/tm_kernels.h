@@ -104,10 +104,16 @@ enum Relax2Subset { R2_ALL = 0, R2_BORDER = 1, R2_INSIDE_A = 2, R2_INSIDE_B = 3,
 // itself at 3 workgroups per CU (see Smoother::inside_lds).
 // wait: the workgroups spin (one thread each, with sleeps) until *counter >= target before they touch memory -- what a
 // launch_queue_wait in front of the launch would do, without the launch (border passes: a few dozen workgroups).
+// Time limit of a device-side wait in ticks of the constant 100 MHz clock: a hang guard for a neighbouring rank that never shows up
+// (its exchange kernel would spin for ever as well), NOT what decides whether two queues may wait for each other -- that is
+// Smoother::queue_self_test, once per handle, with QUEUE_SELF_TEST_TICKS.
+constexpr long long QUEUE_WAIT_TICKS = 30LL * 100000000LL;      // 30 s
+constexpr long long QUEUE_SELF_TEST_TICKS = 500000LL;            // 5 ms
 struct QueueWait {
     const uint32_t* counter = nullptr;
     uint32_t target = 0;
     uint32_t* error = nullptr;
+    long long limit_ticks = QUEUE_WAIT_TICKS;
 };
 hipError_t launch_relax2_block(const Relax2Block& a, int rows_per_chunk, int dot, int subset, hipStream_t stream, size_t lds_bytes = 0,
                                const QueueWait* wait = nullptr);
@@ -193,8 +199,9 @@ hipError_t launch_edge_rhs(const EdgeRowsDev& e, const double2* xk, const double
 // ---- ordering between two queues without barrier packets: one-wave kernels.  signal: *counter += 1 once everything before it in
 // its queue is complete and visible device-wide; wait: returns once *counter >= target (gives up after tens of seconds and sets *error).
 hipError_t launch_queue_signal(uint32_t* counter, hipStream_t stream);
-hipError_t launch_queue_wait(const uint32_t* counter, uint32_t target, uint32_t* error, hipStream_t stream);
-hipError_t launch_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error, hipStream_t stream);
+hipError_t launch_queue_wait(const uint32_t* counter, uint32_t target, uint32_t* error, hipStream_t stream, long long limit_ticks = QUEUE_WAIT_TICKS);
+hipError_t launch_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error, hipStream_t stream,
+                                    long long limit_ticks = QUEUE_WAIT_TICKS);
 
 // ---- reductions: sum partial rows [nwg][MAX_PARTIALS] in fixed order into red[MAX_PARTIALS]
 hipError_t launch_finalize(const double* partials, int nwg, double* red, hipStream_t stream);

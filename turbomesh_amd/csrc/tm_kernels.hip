@@ -880,26 +880,29 @@ __global__ __launch_bounds__(256) void k_relax2(Relax2Block a, int RI, int nSG, 
 // Ordering against another queue from inside a kernel (Smoother::relax_pairs_pipelined): every workgroup of a WAITED launch spins
 // on the counter before it touches memory, then acquires at agent scope (the producer's kernels ended with a release); the first
 // thread of a SIGNALLING launch publishes that everything in front of the launch in its queue is complete.
-// One thread's wait for `*counter >= target`: relaxed polls with sleeps.  The limit is generous (tens of seconds: the first exchange of
-// a new communicator sets up its connections and can take seconds, and everything queued behind it waits that long); a wait that
-// runs into it raises *error and gives up, and so does every later wait of the pass at once (it looks at *error first and every
-// 4096 polls) -- a pass whose ordering failed drains in seconds and returns TM_E_HIP instead of holding the device for
-// (number of waits) x the limit.
-__device__ __forceinline__ void spin_until(const uint32_t* counter, uint32_t target, uint32_t* error) {
+// One thread's wait for `*counter >= target`: relaxed polls with sleeps, bounded in TIME on the constant 100 MHz clock (wall_clock64; a
+// poll count would shrink and stretch with the shader clock).  The limit is a hang guard, not an ordering mechanism: whether the two
+// queues of a handle can wait for each other at all is settled once, at creation, by Smoother::queue_self_test (limit: milliseconds);
+// inside a pass a wait can legitimately last as long as a neighbouring RANK takes to join the exchange in front of it, so the default is
+// tens of seconds (QUEUE_WAIT_TICKS).  A wait that runs into its limit raises *error and gives up, and so does every later wait of the
+// pass at once (it looks at *error first and every 256 polls) -- the pass drains and returns TM_E_HIP instead of holding the device.
+__device__ __forceinline__ void spin_until(const uint32_t* counter, uint32_t target, uint32_t* error, long long limit_ticks) {
     if (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
+    const long long t0 = wall_clock64();
     unsigned polls = 0;
     while (__hip_atomic_load(counter, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < target) {
         __builtin_amdgcn_s_sleep(16);
         ++polls;
-        if ((polls & 4095u) == 0u && __hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
-        if (polls > (1u << 25)) {   // fail the pass rather than hang the device
+        if ((polls & 255u) != 0u) continue;
+        if (__hip_atomic_load(error, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) break;
+        if (wall_clock64() - t0 > limit_ticks) {   // fail the pass rather than hang the device
             __hip_atomic_store(error, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             break;
         }
     }
 }
 __device__ __forceinline__ void queue_wait_in_kernel(const QueueWait& w) {
-    if (threadIdx.x == 0) spin_until(w.counter, w.target, w.error);
+    if (threadIdx.x == 0) spin_until(w.counter, w.target, w.error, w.limit_ticks);
     __syncthreads();
     __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
 }
@@ -1477,7 +1480,7 @@ std::vector<int32_t> relax2_border_tiles(int ni, int nj, int RI, int dyn) {
 hipError_t launch_relax2_block(const Relax2Block& a, int RI, int dot, int subset, hipStream_t st, size_t lds, const QueueWait* wait) {
     const int nstrips = (a.nj - 1 + 59) / 60;
     const int nSG = (nstrips + 3) / 4, nRC = relax2_nchunks(a.ni, RI);
-    if (subset == R2_BORDER && a.nborder == 0) return wait ? launch_queue_wait(wait->counter, wait->target, wait->error, st) : hipSuccess;
+    if (subset == R2_BORDER && a.nborder == 0) return wait ? launch_queue_wait(wait->counter, wait->target, wait->error, st, wait->limit_ticks) : hipSuccess;
     const dim3 grid(subset == R2_BORDER ? a.nborder : nSG * nRC), block(256);
     const bool w1 = a.omega == 1.0;
     const bool nts = a.store_nt != 0;
@@ -1535,7 +1538,7 @@ hipError_t launch_relax2_blocks(const Relax2Block* blocks, const int* rows_per_c
         const hipError_t rc = hipGetLastError();
         if (rc != hipSuccess) return rc;
     }
-    if (wait && !waited) return launch_queue_wait(wait->counter, wait->target, wait->error, st);   // nothing to launch: the wait alone
+    if (wait && !waited) return launch_queue_wait(wait->counter, wait->target, wait->error, st, wait->limit_ticks);   // nothing to launch: the wait alone
     return hipSuccess;
 }
 #undef TM_R2_DISPATCH
@@ -2253,27 +2256,27 @@ __global__ __launch_bounds__(64) void k_queue_signal(uint32_t* counter) {
     // the kernels before this one in the queue have completed (in-order queue, end-of-kernel release); publish at agent scope
     if (threadIdx.x == 0) __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
 }
-__global__ __launch_bounds__(64) void k_queue_wait(const uint32_t* counter, uint32_t target, uint32_t* error) {
+__global__ __launch_bounds__(64) void k_queue_wait(const uint32_t* counter, uint32_t target, uint32_t* error, long long limit_ticks) {
     // relaxed polls (an acquire per poll would invalidate this XCD's L2 every microsecond under the interior pass); the kernels
     // behind this one start with the usual start-of-kernel acquire and see what the signalling queue had completed
-    if (threadIdx.x == 0) spin_until(counter, target, error);
+    if (threadIdx.x == 0) spin_until(counter, target, error, limit_ticks);
 }
 // both in one launch (a kernel boundary less on the handle's stream): announce what precedes, then wait for the other queue
-__global__ __launch_bounds__(64) void k_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error) {
+__global__ __launch_bounds__(64) void k_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error, long long limit_ticks) {
     if (threadIdx.x != 0) return;
     __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
-    spin_until(other, target, error);
+    spin_until(other, target, error, limit_ticks);
 }
-hipError_t launch_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error, hipStream_t st) {
-    hipLaunchKernelGGL(k_queue_signal_wait, dim3(1), dim3(64), 0, st, counter, other, target, error);
+hipError_t launch_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error, hipStream_t st, long long limit_ticks) {
+    hipLaunchKernelGGL(k_queue_signal_wait, dim3(1), dim3(64), 0, st, counter, other, target, error, limit_ticks);
     return hipGetLastError();
 }
 hipError_t launch_queue_signal(uint32_t* counter, hipStream_t st) {
     hipLaunchKernelGGL(k_queue_signal, dim3(1), dim3(64), 0, st, counter);
     return hipGetLastError();
 }
-hipError_t launch_queue_wait(const uint32_t* counter, uint32_t target, uint32_t* error, hipStream_t st) {
-    hipLaunchKernelGGL(k_queue_wait, dim3(1), dim3(64), 0, st, counter, target, error);
+hipError_t launch_queue_wait(const uint32_t* counter, uint32_t target, uint32_t* error, hipStream_t st, long long limit_ticks) {
+    hipLaunchKernelGGL(k_queue_wait, dim3(1), dim3(64), 0, st, counter, target, error, limit_ticks);
     return hipGetLastError();
 }
 

@@ -146,8 +146,15 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     if (!o) throw TmError(TM_E_ARG, "null solver option");
     if (o->tag != TM_SOLVER_HIP)
         throw TmError(TM_E_UNSUPPORTED, "ExternalSolverNotEnabled: libtm_hip serves only solver tag `hip` (gmres/bicgstab/umfpack/petsc stay on the Zig side)");
-    if (o->inner != TM_INNER_BICGSTAB && o->inner != TM_INNER_RELAX && o->inner != TM_INNER_MG_BICGSTAB) throw TmError(TM_E_ARG, "unknown inner strategy");
+    if (o->inner != TM_INNER_BICGSTAB && o->inner != TM_INNER_RELAX && o->inner != TM_INNER_MG_BICGSTAB && o->inner != TM_INNER_AUTO)
+        throw TmError(TM_E_ARG, "unknown inner strategy");
     opt = *o;
+    if (opt.inner == TM_INNER_AUTO) {   // size-aware choice, from the global topology alone (include/tm_hip.h)
+        uint64_t largest = 0;
+        if (mesh && mesh->blocks)
+            for (uint64_t b = 0; b < mesh->nblocks; ++b) largest = std::max<uint64_t>(largest, mesh->blocks[b].ni * mesh->blocks[b].nj);
+        opt.inner = largest >= AUTO_MG_MIN_BLOCK_NODES ? TM_INNER_MG_BICGSTAB : TM_INNER_BICGSTAB;
+    }
     if (!(opt.atol > 0)) opt.atol = 0.0;
     if (opt.check_every == 0) opt.check_every = (opt.inner == TM_INNER_MG_BICGSTAB) ? 1 : 8;   // a multigrid-preconditioned iteration costs ~100x a poll
     if (!(opt.omega > 0)) opt.omega = 1.0;
@@ -1169,6 +1176,65 @@ std::vector<int> Smoother::relax3_rows_of_owned_blocks() const {
     return rows;
 }
 
+// ---- the second queue of a pipelined pass and how it is ordered against the handle's stream (see tm_smoother.hpp)
+void Smoother::ensure_side() {
+    if (side) return;
+    int least = 0, greatest = 0;   // the chain is latency-critical: let its kernels overtake queued interior workgroups
+    HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
+    HIPCHK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest));
+    HIPCHK(hipEventCreateWithFlags(&ev_to_side, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_to_main, hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_inside[0], hipEventDisableTiming));
+    HIPCHK(hipEventCreateWithFlags(&ev_inside[1], hipEventDisableTiming));
+    if (pair_sync_events) queue_ordering = ORDER_EVENTS_REQUESTED;
+    else queue_ordering = queue_self_test() ? ORDER_COUNTERS : ORDER_EVENTS_SELF_TEST;
+}
+
+// One announce-and-wait round between the handle's stream and `side`, in both directions at once -- the very pair of kernels the triple
+// schedule enqueues per triple -- with a limit of 5 ms.  Both streams are drained first, so the only thing that can keep either kernel
+// from starting is the other one spinning in front of it in a SHARED hardware queue (a caller's stream of the same priority class as
+// `side` with the runtime's per-priority queue pool exhausted, GPU_MAX_HW_QUEUES=1, ...): then the first kernel runs into its limit,
+// raises the error word and the handle orders its queues with events from the start.  ~0.1 ms once per handle when it passes.
+bool Smoother::queue_self_test() {
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipStreamSynchronize(side));
+    uint32_t* a = sync_flags + 8;    // words 8..11: the test's own counters (the passes use 0..3)
+    uint32_t* b = sync_flags + 9;
+    uint32_t* err = sync_flags + 10;
+    HIPCHK(hipMemsetAsync(sync_flags + 8, 0, sizeof(uint32_t) * 4, stream));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(launch_queue_signal_wait(a, b, 1u, err, stream, QUEUE_SELF_TEST_TICKS));
+    HIPCHK(launch_queue_signal_wait(b, a, 1u, err, side, QUEUE_SELF_TEST_TICKS));
+    HIPCHK(hipStreamSynchronize(stream));
+    HIPCHK(hipStreamSynchronize(side));
+    uint32_t h[4] = {0, 0, 0, 0};
+    HIPCHK(hipMemcpy(h, sync_flags + 8, sizeof(h), hipMemcpyDeviceToHost));
+    return h[2] == 0u && h[0] == 1u && h[1] == 1u;
+}
+
+bool Smoother::use_counters() {
+    if (queue_ordering == ORDER_EVENTS_REQUESTED || queue_ordering == ORDER_EVENTS_SELF_TEST) return false;
+    if (g_multirank_handles.load() > 1) {   // several multi-rank handles in ONE process (the virtual-rank tests) wait for each other through shared queues
+        queue_ordering = ORDER_EVENTS_SHARED_PROCESS;
+        return false;
+    }
+    queue_ordering = ORDER_COUNTERS;
+    return true;
+}
+
+// The first exchange of a handle runs alone, with the host waiting for it: a transport sets up its connections inside its first
+// transfer (RCCL: seconds, on the host, inside ncclGroupEnd) and the ranks of a job reach their first pass at different times.  Everything
+// that skew would otherwise be spent by a device-side wait of the first pass; with it out of the way the waits of a pass only ever cover a
+// neighbour's kernels and its host's jitter.  The rows that travel are X's own (the pass sends them again).
+void Smoother::warm_transport() {
+    if (transport_warm) return;
+    transport_warm = true;
+    if (!(has_hooks && (n_send > 0 || n_ghost > 0))) return;
+    exchange(X, side);
+    exchange_finish(side);
+    HIPCHK(hipStreamSynchronize(side));
+}
+
 // Three sweeps in one pass (K2x3, all perimeter rows fixed): X^(k+3) = S(S(S(X^k))), bit-identical to three single sweeps
 void Smoother::relax_triple(bool want_partials) {
     const int dot = want_partials ? DOT_DELTA : DOT_NONE;
@@ -1203,25 +1269,18 @@ void Smoother::relax_triple(bool want_partials) {
 // Several ranks (LocalPlan::triple_halo): X^k of the depth-3 ghost set travels once per triple in front of level 1, which also
 // evaluates the depth-2 ghost rows, level 2 the depth-1 ones -- with their owners' row definitions, so with their owners' bits.
 void Smoother::relax_triples_coupled(uint64_t ntriples, bool want_partials_last) {
-    if (!side) {
-        int least = 0, greatest = 0;
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest));
-        HIPCHK(hipEventCreateWithFlags(&ev_to_side, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ev_to_main, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ev_inside[0], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ev_inside[1], hipEventDisableTiming));
-    }
+    ensure_side();
     // Ordering between the two queues inside the loop: counters in device memory and one-wave signal / wait kernels, as in
     // relax_pairs_pipelined (an event record / wait pair stalls its queue for ~10 us on this part, twice per triple: at 2048^2 that is
     // a third of the interior pass); events when several multi-rank handles share the process or TM_PAIR_SYNC=events asks for them.
     // A waiter's producer is always enqueued before it in host order.
-    const bool use_flags = !pair_sync_events && g_multirank_handles.load() <= 1;
+    const bool use_flags = use_counters();
     uint32_t* chain_done = sync_flags;        // level-3 passes completed (side queue)
     uint32_t* inside_done = sync_flags + 1;   // K2x3 passes completed (handle's stream)
     uint32_t* sync_err = sync_flags + 2;
     if (use_flags) HIPCHK(hipMemsetAsync(sync_flags, 0, sizeof(uint32_t) * 4, stream));
     fence(stream, side, ev_to_side);   // X (and the cleared counters) complete on the handle's stream
+    warm_transport();
     std::vector<Relax2Block> blocks(lp.owned_blocks.size());
     for (uint64_t q = 0; q < ntriples; ++q) {
         const int dot = (q + 1 == ntriples && want_partials_last) ? DOT_DELTA : DOT_NONE;
@@ -1244,10 +1303,9 @@ void Smoother::relax_triples_coupled(uint64_t ntriples, bool want_partials_last)
         // handle's stream: K2x3 of triple q needs the chain of triple q-1 (its level 3 wrote rows of X).  With counters, ONE one-wave
         // kernel per queue and triple does both jobs: starting behind K2x3 of triple q-1 it announces that pass (inside_done = q), then
         // waits for the chain of triple q-1 (chain_done >= q); its twin on the chain's queue announces the chain and waits for the pass.
-        // Both announce before they wait, so neither can hold the other up -- PROVIDED the two streams sit on different hardware queues
-        // (the chain's stream has the highest priority, the handle's is the caller's: distinct queue pools in the runtime); if they
-        // ever shared one in-order queue the second could not start, the first would run into its limit, and the handle reports
-        // TM_E_HIP (bench.py then re-creates every rank's handle with TM_PAIR_SYNC=events).
+        // Both announce before they wait, so neither can hold the other up -- PROVIDED the two streams sit on different hardware queues:
+        // on one in-order queue the second could not start while the first spins.  That is not assumed: ensure_side() ran exactly this
+        // pair of kernels once when `side` was created (queue_self_test, limit 5 ms) and use_counters() is false when it failed.
         if (q > 0) {
             if (use_flags) HIPCHK(launch_queue_signal_wait(inside_done, chain_done, static_cast<uint32_t>(q), sync_err, stream));
             else HIPCHK(hipStreamWaitEvent(stream, ev_to_main, 0));
@@ -1298,15 +1356,7 @@ void Smoother::relax_pair(bool want_partials) {
 // bit for bit), so E2 finds its remote operands in M without a second exchange.
 // Buffers: A = complete input, Bf = output, M = perimeter + ring (+ ghost rows) of the intermediate field; A and Bf swap per pair.
 void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
-    if (!side) {
-        int least = 0, greatest = 0;   // the chain is latency-critical: let its kernels overtake queued interior workgroups
-        HIPCHK(hipDeviceGetStreamPriorityRange(&least, &greatest));
-        HIPCHK(hipStreamCreateWithPriority(&side, hipStreamNonBlocking, greatest));
-        HIPCHK(hipEventCreateWithFlags(&ev_to_side, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ev_to_main, hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ev_inside[0], hipEventDisableTiming));
-        HIPCHK(hipEventCreateWithFlags(&ev_inside[1], hipEventDisableTiming));
-    }
+    ensure_side();
     // Ordering between the two queues INSIDE the loop.  hipEventRecord / hipStreamWaitEvent are barrier packets, and every one of
     // them stalls its queue for 7-12 us on this part (rocprofv3 traces under profiles/): 10 % of a 4096^2 pass on the handle's
     // stream, a fifth of the chain of a 2048^2 pass.  So a dependency is a one-wave kernel on either side instead: the producer queue
@@ -1316,7 +1366,7 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
     // deadlock even if both streams share a hardware queue; a wait that is not met within tens of seconds raises sync_flags[2] and
     // the pass fails with TM_E_HIP instead of hanging the device.  Several multi-rank handles in ONE process (the virtual-rank tests) could
     // block each other through shared hardware queues: they use events.
-    const bool use_flags = !pair_sync_events && g_multirank_handles.load() <= 1;
+    const bool use_flags = use_counters();
     uint32_t* border_done = sync_flags;
     uint32_t* inside_done = sync_flags + 1;
     uint32_t* sync_err = sync_flags + 2;
@@ -1368,6 +1418,7 @@ void Smoother::relax_pairs_pipelined(uint64_t npairs, bool want_partials_last) {
     // K2x2 parts read X (input) and write U (output) through relax2_launch: keep X/U pointing at the pair in flight
     int dot = (npairs == 1 && want_partials_last) ? DOT_DELTA : DOT_NONE;
     fence(stream, side, ev_to_side);   // X is complete on the main stream
+    warm_transport();
     exchange_on_side(X);
     edge_on_side(e1, X, M, DOT_NONE);    // E1g(0): perimeter rows (own + ghost) of the intermediate field
     relax2_launch(R2_INSIDE, false, dot);

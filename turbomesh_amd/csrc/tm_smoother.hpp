@@ -159,6 +159,19 @@ struct Smoother {
     hipStream_t side = nullptr;
     hipEvent_t ev_to_side = nullptr, ev_to_main = nullptr, ev_inside[2] = {nullptr, nullptr};
     void fence(hipStream_t from, hipStream_t to, hipEvent_t ev);
+    // How the two queues of a pipelined pass (interior pass on the handle's stream, chain on `side`) are ordered against each other.
+    // Counters in device memory + one-wave announce / wait kernels need the two streams on DIFFERENT hardware queues (a waiter whose
+    // producer sits behind it in the same in-order queue never sees it start); HIP does not promise that, so the handle finds out: once,
+    // when `side` is created, one announce-and-wait round in both directions with a limit of milliseconds (queue_self_test).  Events
+    // (barrier packets, ~10 us per hop, no assumption) are used when the test fails, when TM_PAIR_SYNC=events asks for them, and when
+    // several multi-rank handles share the process.
+    enum { ORDER_UNDECIDED = -1, ORDER_COUNTERS = 0, ORDER_EVENTS_REQUESTED = 1, ORDER_EVENTS_SHARED_PROCESS = 2, ORDER_EVENTS_SELF_TEST = 3 };
+    int queue_ordering = ORDER_UNDECIDED;
+    void ensure_side();              // creates `side` and its events, runs the self-test (first use)
+    bool queue_self_test();          // true = the two streams ran side by side
+    bool use_counters();             // the decision for the pass being enqueued
+    bool transport_warm = false;     // the first exchange of a handle runs alone and synchronised (connections are set up inside it)
+    void warm_transport();
     void relax_pairs_pipelined(uint64_t npairs, bool want_partials_last);
     uint32_t* sync_flags = nullptr;   // device counters of the cross-queue dependencies of a sweep pair (k_queue_signal / k_queue_wait)
     uint32_t* h_flags = nullptr;      // pinned
@@ -208,6 +221,9 @@ struct Smoother {
 // 6.5e-11 at 2049^2 and 6e-10 at 4096^2 with rtol 1e-14.  Hence rtol = 7.5e-9 / nodes, between 1e-16 and 1e-14: every size lands
 // at <= 3e-11, for 0-40 % more inner iterations on the large meshes (the recurrence residual keeps falling; no stagnation seen down
 // to 1e-16).  The iteration cap grows with the mesh too: BiCGStab with the diagonal alone needs ~3-5 sqrt(nodes) iterations.
+// TM_INNER_AUTO: the multigrid-preconditioned solve from this many nodes in the largest block on (include/tm_hip.h)
+constexpr uint64_t AUTO_MG_MIN_BLOCK_NODES = 100000;
+
 inline double default_rtol(double nodes) {
     const double r = 7.5e-9 / (nodes > 1.0 ? nodes : 1.0);
     return r > 1e-14 ? 1e-14 : (r < 1e-16 ? 1e-16 : r);

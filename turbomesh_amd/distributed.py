@@ -260,10 +260,15 @@ class RcclHooks:
 
     @staticmethod
     def _librccl_path():
+        """The RCCL this process should use: $TM_RCCL_LIB when set (a site's own build), else the copy torch ships and has already
+        loaded (one RCCL per process), else the library's default search (NULL)."""
         import os
 
         import torch
 
+        env = os.environ.get("TM_RCCL_LIB")
+        if env:
+            return env.encode()
         path = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
         return path.encode() if os.path.exists(path) else None
 

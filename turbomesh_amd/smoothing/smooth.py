@@ -74,6 +74,7 @@ class Smoother:
                                                    C.c_void_p(stream) if stream else None, C.byref(h)))
         self._h = h
         self.dof = int(_capi.lib().tm_smoother_dof(self._h))
+        self.inner = _solver.Inner(int(_capi.lib().tm_smoother_inner(self._h)))   # what Inner.auto resolved to
 
     def close(self):
         if getattr(self, "_h", None):
@@ -155,6 +156,14 @@ class Smoother:
         n = C.c_uint64(0)
         _capi.check(_capi.lib().tm_smoother_profile_read(self._h, C.byref(ms), C.byref(timed), C.byref(n)))
         return ms.value, int(timed.value), int(n.value)
+
+    QUEUE_ORDERING = {-1: "none", 0: "counters", 1: "events (TM_PAIR_SYNC=events)", 2: "events (several multi-rank handles in this process)",
+                      3: "events (self-test: both streams on one hardware queue)"}
+
+    def queue_ordering(self):
+        """How the handle orders the two queues of a pipelined pass (include/tm_hip_diag.h): code and its meaning."""
+        code = int(_capi.lib().tm_smoother_queue_ordering(self._h))
+        return code, self.QUEUE_ORDERING.get(code, "?")
 
     def control_function(self):
         out = np.empty((self.dof, 2))

@@ -33,6 +33,7 @@ class Inner(enum.IntEnum):
     bicgstab = _capi.TM_INNER_BICGSTAB   # Picard + matrix-free BiCGStab on D^-1 A
     relax = _capi.TM_INNER_RELAX         # one fused Jacobi elliptic sweep per outer iteration
     mg_bicgstab = _capi.TM_INNER_MG_BICGSTAB   # bicgstab, right-preconditioned by one multigrid V-cycle per block
+    auto = _capi.TM_INNER_AUTO           # mg_bicgstab when the largest block has >= 100 000 nodes, bicgstab below (decided at create)
 
 
 @dataclass
