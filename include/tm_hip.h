@@ -119,6 +119,11 @@ enum {
                                 (damped Jacobi, full weighting, rediscretised Winslow operator on vertex-coarsened levels;
                                 perimeter rows keep the identity).  Same Picard iterates, far fewer inner iterations on
                                 large blocks: what makes "to 1e-8 residual at 4096^2" practical               */
+    TM_INNER_GMRES = 4,      /* the Picard outer iteration with the reference's OTHER Krylov solver restated on the device: restarted GMRES(30),
+                                left-preconditioned with the diagonal, modified Gram-Schmidt Arnoldi, Givens rotations (GMRES.zig:300-423,
+                                510-524; restart 30 as GMRES.zig:21).  Same scale-aware stop test as TM_INNER_BICGSTAB.  What a front end
+                                maps "solver": {"gmres": {"preconditioner": "diagonal"}} of an input file to; ILU(0) (GMRES.zig:199-298) is a
+                                sequential recurrence with no device counterpart                                                      */
     TM_INNER_AUTO = 3        /* resolved when the handle is created, from the mesh alone (every rank of a job decides alike):
                                 TM_INNER_MG_BICGSTAB when the largest block has >= 100 000 nodes, TM_INNER_BICGSTAB below -- on the
                                 reference's example meshes (T106 / LS89: 8 blocks of 10^2..10^4 nodes) every multigrid level is a handful

@@ -183,4 +183,14 @@ def test_cli_runs_the_t106_input_with_the_hip_solver(tmp_path):
     assert "inner strategy: bicgstab (chosen from the block sizes)" in r.stderr, r.stderr[-2000:]
     blocks = output.read_plot3d(out)
     assert [(b[0], b[1]) for b in blocks] == [(221, 41), (121, 41), (11, 41), (11, 51), (121, 41), (161, 11), (21, 91), (11, 131)]
+    # --hip file: the solver the JSON names ("gmres" + "ilu0", examples/T106/T106.json:28-41) honoured by its device counterpart -- GMRES(30) as
+    # GMRES.zig:300-423 with the diagonal in ILU(0)'s place -- and the result is the same mesh (a Krylov method changes the route only)
+    out2 = str(tmp_path / "t106_gmres.xyz")
+    r = subprocess.run([sys.executable, "-m", "turbomesh_amd", cfg, "--hip", "file", "--iterations", "2", "--output", out2], capture_output=True, text=True,
+                       timeout=600, cwd=GOLD, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "inner strategy: gmres" in r.stderr and "ilu0 has no device counterpart" in r.stderr, r.stderr[-2000:]
+    blocks2 = output.read_plot3d(out2)
+    for a, b in zip(blocks, blocks2):
+        assert np.sqrt(np.mean((a[2] - b[2]) ** 2 + (a[3] - b[3]) ** 2)) <= 1e-10
     assert all(np.isfinite(b[2]).all() and np.isfinite(b[3]).all() for b in blocks)

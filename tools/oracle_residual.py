@@ -1,0 +1,96 @@
+#!/usr/bin/env python3
+"""Full-size, kernel-independent check of a Picard iterate (BASELINE configs[1]: the perturbed n x n block, n = 4096 by default).
+
+  1. X^1 on the GPU by both routes of the library with default options: Picard + BiCGStab (diagonal) and Picard + multigrid-preconditioned
+     BiCGStab (matrix-free kernels k_apply_vk / k_mg_pair, tm_plan.cpp's perimeter rows).
+  2. The reference's system at X^0 assembled by the FAITHFUL oracle on the host (oracle/orc_system.cpp = smooth.zig:309-385, 923-1113): CSR + rhs.
+  3. || D^-1 (b - A(X^0) X^1) ||_2 / || D^-1 b ||_2 in 80-bit extended precision (tests/residual_check.py), per route.
+  4. (--csr) a THIRD route that shares no operator kernel with the other two: the oracle's CSR itself solved on the GPU through seam 2
+     (tm_csr_solve: CSR mat-vec kernels of csrc/tm_csr.hip) from the same initial guess; RMS distance of the three X^1 from one another.
+
+usage: oracle_residual.py [n = 4096] [--csr] [--out file]      (host memory: ~6 GB at 4096^2)"""
+import ctypes as C
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import numpy as np
+
+
+def main():
+    args = [a for a in sys.argv[1:] if not a.startswith("--")]
+    n = int(args[0]) if args else 4096
+    want_csr = "--csr" in sys.argv
+    out_path = sys.argv[sys.argv.index("--out") + 1] if "--out" in sys.argv else None
+    from tests import residual_check as rc
+    from turbomesh_amd import _capi, configs
+    from turbomesh_amd.discrete import Mesh
+    from turbomesh_amd.smoothing import smooth, solver
+
+    lines = []
+
+    def say(s):
+        print(s, flush=True)
+        lines.append(s)
+
+    x0 = configs.single_block(n, n, perturb=0.25).blocks[0].points.data.copy()
+    nodes = n * n
+    rtol_default = min(1e-14, max(1e-16, 7.5e-9 / nodes))
+    say(f"# perturbed {n} x {n} block (displacement 0.25 h, seed 12345), one Picard iteration from X^0, default options; default inner rtol {rtol_default:.2e}")
+
+    iterates = {}
+    for name, inner in (("bicgstab", solver.Inner.bicgstab), ("mg_bicgstab", solver.Inner.mg_bicgstab)):
+        m = Mesh()
+        m.addBlock("b", configs.block_from_array(x0.copy()))
+        t0 = time.perf_counter()
+        with smooth.Smoother(m, solver.Option.hip(inner=inner)) as sm:
+            st = sm.iterate(1)
+            sm.download()
+        iterates[name] = m.blocks[0].points.data.reshape(-1, 2).copy()
+        say(f"route {name:12s}: {st['inner_iterations']:6d} inner iterations, {time.perf_counter() - t0:6.2f} s, not_converged {st['not_converged']}")
+
+    t0 = time.perf_counter()
+    p, i, v, b = rc.assemble([x0])
+    say(f"oracle-assembled system (smooth.zig:923-1113 restated, host): {len(p) - 1} rows, {len(v)} non-zeros, {time.perf_counter() - t0:.1f} s")
+
+    if want_csr:
+        x = x0.reshape(-1, 2)
+        xs, ys = np.ascontiguousarray(x[:, 0]).copy(), np.ascontiguousarray(x[:, 1]).copy()
+        bx, by = np.ascontiguousarray(b[:, 0]), np.ascontiguousarray(b[:, 1])
+        opt = solver.Option.hip().c_struct()
+        st = _capi.tm_stats()
+        ip = C.POINTER(C.c_int32)
+        t0 = time.perf_counter()
+        rcode = _capi.lib().tm_csr_solve(len(p) - 1, p.ctypes.data_as(ip), i.ctypes.data_as(ip), _capi.f64ptr(v), None, _capi.f64ptr(bx), _capi.f64ptr(by),
+                                         _capi.f64ptr(xs), _capi.f64ptr(ys), C.byref(opt), C.byref(st))
+        if rcode < 0:
+            _capi.check(rcode)
+        iterates["csr_seam2"] = np.stack([xs, ys], axis=1)
+        say(f"route csr_seam2   : {st.inner_iterations:6d} inner iterations, {time.perf_counter() - t0:6.2f} s (tm_csr_solve on the oracle's CSR: csrc/tm_csr.hip, no matrix-free kernel), rc {rcode}")
+
+    worst = 0.0
+    for name, x1 in iterates.items():
+        t0 = time.perf_counter()
+        both, per = rc.relative_residual(p, i, v, b, x1)
+        both64, _ = rc.relative_residual(p, i, v, b, x1, dtype=np.float64)
+        worst = max(worst, both)
+        say(f"true scaled residual of X^1 [{name:12s}] vs the oracle-assembled system: {both:.3e} (x {per[0]:.3e}, y {per[1]:.3e}); the same evaluated in fp64: {both64:.3e}   ({time.perf_counter() - t0:.0f} s)")
+    both0, _ = rc.relative_residual(p, i, v, b, x0.reshape(-1, 2))
+    say(f"for scale: X^0 itself {both0:.3e}; a residual EVALUATED in fp64 cannot read below ~ eps sqrt(rows) |x| / ||D^-1 b||")
+    names = list(iterates)
+    for a in range(len(names)):
+        for c in range(a + 1, len(names)):
+            d = iterates[names[a]] - iterates[names[c]]
+            say(f"rms distance X^1[{names[a]}] - X^1[{names[c]}]: {float(np.sqrt(np.mean(d * d))):.3e}")
+    say(f"ladder's estimate of the error of the diagonal-only solve at this size (DESIGN.md section 5): 4e-17 .. 1e-16 x nodes x (rtol / 1e-14) = "
+        f"{4e-17 * nodes * rtol_default / 1e-14:.1e} .. {1e-16 * nodes * rtol_default / 1e-14:.1e}")
+    if out_path:
+        with open(out_path, "a") as f:
+            f.write("\n".join(lines) + "\n")
+    return worst
+
+
+if __name__ == "__main__":
+    main()

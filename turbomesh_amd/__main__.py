@@ -21,8 +21,9 @@ from .smoothing import smooth, solver
 def main(argv=None):
     ap = argparse.ArgumentParser(prog="python -m turbomesh_amd", description=__doc__, formatter_class=argparse.RawDescriptionHelpFormatter)
     ap.add_argument("config", help="input file in the reference's JSON schema (examples/T106/T106.json)")
-    ap.add_argument("--hip", nargs="?", const="auto", choices=["auto", "bicgstab", "mg_bicgstab", "relax"],
-                    help="use the hip solver with this inner strategy instead of the solver named in the file")
+    ap.add_argument("--hip", nargs="?", const="auto", choices=["auto", "bicgstab", "mg_bicgstab", "gmres", "relax", "file"],
+                    help="use the hip solver with this inner strategy instead of the solver named in the file; `file` = the device counterpart of "
+                         "the solver the file names (gmres -> GMRES(30) on the device, bicgstab -> BiCGStab; ilu0 -> diagonal)")
     ap.add_argument("--iterations", type=int, help="override smoothing.iterations")
     ap.add_argument("--output", help="override the output file (.xyz / .p3d: multi-block PLOT3D)")
     ap.add_argument("--until", type=float, metavar="TOL",
@@ -32,7 +33,11 @@ def main(argv=None):
 
     with open(args.config) as f:
         inp = tm_input.Input.parse(f.read())
-    if args.hip:
+    if args.hip == "file":
+        inp.solver, note = inp.solver.served_by_hip()
+        if note:
+            logging.getLogger("smoothing").warning(note)
+    elif args.hip:
         inp.solver = solver.Option.hip(inner=getattr(solver.Inner, args.hip))
     if inp.solver.tag != solver.Tag.hip:
         sys.exit(f"error.ExternalSolverNotEnabled: solver `{inp.solver.tag.name}` is served by the Zig program; "

@@ -21,7 +21,7 @@ TM_E_SIZE, TM_E_TOPOLOGY, TM_E_MISMATCH, TM_E_OVERFLOW, TM_E_UNSUPPORTED, TM_E_A
 _ERR_NAMES = {-1: "InconsistentSize", -2: "Topology", -3: "Mismatch", -4: "Overflow", -5: "ExternalSolverNotEnabled", -6: "Argument",
               -7: "OutOfMemory", -8: "Hip", -9: "Comm"}
 TM_SOLVER_GMRES, TM_SOLVER_BICGSTAB, TM_SOLVER_UMFPACK, TM_SOLVER_PETSC, TM_SOLVER_HIP = 0, 1, 2, 3, 4
-TM_INNER_BICGSTAB, TM_INNER_RELAX, TM_INNER_MG_BICGSTAB, TM_INNER_AUTO = 0, 1, 2, 3
+TM_INNER_BICGSTAB, TM_INNER_RELAX, TM_INNER_MG_BICGSTAB, TM_INNER_AUTO, TM_INNER_GMRES = 0, 1, 2, 3, 4
 TM_CF_LAPLACE, TM_CF_WHITE = 0, 1
 
 

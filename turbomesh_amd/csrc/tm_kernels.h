@@ -264,6 +264,32 @@ hipError_t launch_xr_update(const LazyScalars& S, double2* u, const double2* p_h
 // the same with s = r - alpha v formed on the fly (s was never stored): reads p, r, v, t, r_hat, u; r is updated in place
 hipError_t launch_xr_update_vs(const LazyScalars& S, double2* u, const double2* p, const double2* v, const double2* t, double2* r, const double2* r_hat,
                                int64_t n, double* partials, hipStream_t stream);
+// ---- GMRES(m) (csrc/tm_gmres.hip; GMRES.zig:300-423): device-resident state of one solve, index = component (0 x, 1 y)
+constexpr int GMRES_M = 30;   // restart length, GMRES.zig:21
+struct GmresScalars {
+    double H[2][(GMRES_M + 1) * GMRES_M];   // Hessenberg columns, h(row, col) at row + (m + 1) col (GMRES.zig:495-497), rotated in place
+    double cs[2][GMRES_M], sn[2][GMRES_M];  // Givens rotations
+    double g[2][GMRES_M + 1];               // rotated right-hand side; |g[j+1]| = the residual norm after column j
+    double y[2][GMRES_M];                   // solution of the triangular system
+    double tol[2], beta[2], resid[2], rr0[2], scale[2];
+    double rtol_initial;
+    int32_t tol_initial[2];
+    int32_t cols_used[2];                   // columns of this cycle the component's update uses
+    int32_t done[2];                        // resid <= tol (the component's solve is over)
+    int32_t scale_skip[2];                  // see k_gm_divide
+    int32_t j, cycle;
+};
+// one modified-Gram-Schmidt step in one pass: w -= red_prev[c] v_prev (and H[row_prev, j] = red_prev), partials = w . v_next (or ||w||^2
+// when v_next == nullptr); v_prev == nullptr: the first step, nothing to subtract yet
+hipError_t launch_gm_mgs(double2* w, const double2* v_prev, const double2* v_next, const double* red_prev, GmresScalars* G, int row_prev, int64_t n,
+                         double* partials, hipStream_t stream);
+hipError_t launch_gm_divide(double2* dst, const double2* src, const GmresScalars* G, int64_t n, hipStream_t stream);   // dst = src / G->scale[c]
+hipError_t launch_gm_update(double2* u, const double2* V, int64_t ld, const GmresScalars* G, int64_t n, hipStream_t stream);   // u += V y
+hipError_t launch_gm_tol(GmresScalars* G, const double* red, double rtol, double atol, hipStream_t stream);
+hipError_t launch_gm_begin(GmresScalars* G, const double* red, hipStream_t stream);
+hipError_t launch_gm_column(GmresScalars* G, const double* red, hipStream_t stream);
+hipError_t launch_gm_backsub(GmresScalars* G, hipStream_t stream);
+
 // K7: partials sum (xk-u)^2 (x,y); xk <- u
 hipError_t launch_residual_copyback(double2* xk, const double2* u, int64_t n, double* partials, hipStream_t stream);
 // gather rows for the halo exchange: dst[k] = src[ids[k]]

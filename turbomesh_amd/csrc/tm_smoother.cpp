@@ -126,6 +126,7 @@ Smoother::~Smoother() {
         if (ev_poll[k]) (void)hipEventDestroy(ev_poll[k]);
     }
     if (h_red) (void)hipHostFree(h_red);
+    if (h_gm) (void)hipHostFree(h_gm);
     if (h_flags) (void)hipHostFree(h_flags);
     for (hipEvent_t e : ev_start) (void)hipEventDestroy(e);
     for (hipEvent_t e : ev_stop) (void)hipEventDestroy(e);
@@ -146,7 +147,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     if (!o) throw TmError(TM_E_ARG, "null solver option");
     if (o->tag != TM_SOLVER_HIP)
         throw TmError(TM_E_UNSUPPORTED, "ExternalSolverNotEnabled: libtm_hip serves only solver tag `hip` (gmres/bicgstab/umfpack/petsc stay on the Zig side)");
-    if (o->inner != TM_INNER_BICGSTAB && o->inner != TM_INNER_RELAX && o->inner != TM_INNER_MG_BICGSTAB && o->inner != TM_INNER_AUTO)
+    if (o->inner != TM_INNER_BICGSTAB && o->inner != TM_INNER_RELAX && o->inner != TM_INNER_MG_BICGSTAB && o->inner != TM_INNER_AUTO && o->inner != TM_INNER_GMRES)
         throw TmError(TM_E_ARG, "unknown inner strategy");
     opt = *o;
     if (opt.inner == TM_INNER_AUTO) {   // size-aware choice, from the global topology alone (include/tm_hip.h)
@@ -211,6 +212,11 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     X = vec();
     U = vec();
     use_mg = opt.inner == TM_INNER_MG_BICGSTAB;
+    if (opt.inner == TM_INNER_GMRES) {   // w / z of GMRES.zig:27-38 in one vector, the basis v_0 .. v_m contiguous behind it
+        r = vec();
+        gm_V = arena.alloc_n<double2>(static_cast<uint64_t>(n_local) * (GMRES_M + 1));
+        gm_S = arena.alloc_n<GmresScalars>(1);
+    }
     if (opt.inner == TM_INNER_BICGSTAB || use_mg) {
         r = vec();
         r_hat = vec();
@@ -606,6 +612,12 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
             HIPCHK(hipEventCreateWithFlags(&ev_poll[k], hipEventDisableTiming));
         }
     HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_red), sizeof(double) * MAX_PARTIALS, hipHostMallocDefault));
+    if (gm_S) {
+        HIPCHK(hipHostMalloc(reinterpret_cast<void**>(&h_gm), sizeof(GmresScalars), hipHostMallocDefault));
+        HIPCHK(hipMemsetAsync(gm_S, 0, sizeof(GmresScalars), stream));
+        HIPCHK(hipMemsetAsync(gm_V, 0, sizeof(double2) * static_cast<size_t>(n_local) * (GMRES_M + 1), stream));
+        HIPCHK(hipMemsetAsync(r, 0, sizeof(double2) * n_local, stream));
+    }
     HIPCHK(hipMemsetAsync(S_buf[0], 0, sizeof(KrylovScalars), stream));
     if (S_buf[1] != S_buf[0]) HIPCHK(hipMemsetAsync(S_buf[1], 0, sizeof(KrylovScalars), stream));
     HIPCHK(hipMemsetAsync(sync_flags, 0, sizeof(uint32_t) * 64, stream));
@@ -1133,6 +1145,89 @@ int Smoother::picard_bicgstab(tm_stats& st) {
     return converged ? 0 : 1;
 }
 
+// Picard outer iteration with GMRES(30) as the inner solver (GMRES.zig:300-423 restated on the device, csrc/tm_gmres.hip): left
+// preconditioning with the diagonal (GMRES.zig:425-431) = K2's MODE_SCALED, modified Gram-Schmidt with one pass per basis vector, Givens
+// rotations and the triangular solve by one-thread kernels on device-resident state, both components together.  Returns like
+// picard_bicgstab: 0 converged, 1 not converged (a warning, GMRES.zig:422), 2 stop_tol already met.
+int Smoother::picard_gmres(tm_stats& st) {
+    if (white && outer_done > 0) white_launch(1);   // system.fill(n): control_function.update for n > 0 (smooth.zig:1107-1110)
+    exchange(X);
+    exchange_finish();
+    HIPCHK(launch_edge_rhs(edge, X, PQ, nullptr, 1, partials, stream));   // ||D^-1 b||^2 -> the tolerance
+    reduce(edge.nwg);
+    HIPCHK(launch_gm_tol(gm_S, red, (opt.flags & TM_OPT_RTOL_INITIAL) ? -opt.rtol : opt.rtol, opt.atol, stream));
+    double2* const W = r;
+    const int64_t ld = n_local;
+    auto V = [&](int k) { return gm_V + static_cast<int64_t>(k) * ld; };
+    auto poll = [&]() {   // the flags of both components, after everything enqueued so far
+        HIPCHK(hipMemcpyAsync(h_gm, gm_S, sizeof(GmresScalars), hipMemcpyDeviceToHost, stream));
+        sync();
+        return h_gm->done[0] == 1 && h_gm->done[1] == 1;
+    };
+    uint64_t it_total = 0;
+    bool converged = false, first = true;
+    while (it_total < opt.max_inner) {
+        // z = D^-1 (b - A x), beta = ||z|| (GMRES.zig:312-319); the warm start is the current field (GMRES.zig:136-153 seeds x_new from the mesh)
+        apply(first ? X : U, W, MODE_RESID, DOT_OUT2, nullptr, X, 0.0, -1);
+        st.operator_sweeps += 1;
+        HIPCHK(launch_gm_begin(gm_S, red, stream));
+        const bool all_done = poll();
+        if (first) {
+            st.scaled_residual_rms = std::sqrt((h_gm->rr0[0] + h_gm->rr0[1]) / (2.0 * static_cast<double>(dof_global)));
+            if (stop_tol > 0.0 && st.scaled_residual_rms <= stop_tol) return 2;
+            HIPCHK(hipMemcpyAsync(U, X, sizeof(double2) * n_local, hipMemcpyDeviceToDevice, stream));
+            first = false;
+        }
+        if (all_done) {
+            converged = true;
+            break;
+        }
+        HIPCHK(launch_gm_divide(V(0), W, gm_S, n_owned, stream));   // v0 = z / beta
+        bool cycle_done = false;
+        for (int j = 0; j < GMRES_M && it_total < opt.max_inner; ++j) {
+            apply(V(j), W, MODE_SCALED, DOT_NONE, nullptr, X, 0.0, -1);   // w = A v_j, z = D^-1 w (GMRES.zig:335-336)
+            st.operator_sweeps += 1;
+            // modified Gram-Schmidt (GMRES.zig:338-345): h_ij = z . v_i, z -= h_ij v_i, i = 0 .. j -- the subtraction of step i - 1 and
+            // the inner product of step i in one pass each; then h_{j+1,j} = ||z|| behind the last subtraction
+            HIPCHK(launch_gm_mgs(W, nullptr, V(0), nullptr, gm_S, 0, n_owned, partials, stream));
+            reduce(nwg_vec);
+            for (int i = 1; i <= j; ++i) {
+                HIPCHK(launch_gm_mgs(W, V(i - 1), V(i), red, gm_S, i - 1, n_owned, partials, stream));
+                reduce(nwg_vec);
+            }
+            HIPCHK(launch_gm_mgs(W, V(j), nullptr, red, gm_S, j, n_owned, partials, stream));
+            reduce(nwg_vec);
+            HIPCHK(launch_gm_column(gm_S, red, stream));                      // rotations, g, |g_{j+1}|, flags (GMRES.zig:347-386)
+            if (j + 1 < GMRES_M + 1) HIPCHK(launch_gm_divide(V(j + 1), W, gm_S, n_owned, stream));   // v_{j+1} = z / h_next unless h_next <= 1e-30
+            it_total += 1;
+            if ((j + 1) % static_cast<int>(opt.check_every) == 0 || j + 1 == GMRES_M || it_total == opt.max_inner) {
+                if (poll()) {
+                    cycle_done = true;
+                    break;
+                }
+            }
+        }
+        HIPCHK(launch_gm_backsub(gm_S, stream));                              // GMRES.zig:394-409
+        HIPCHK(launch_gm_update(U, gm_V, ld, gm_S, n_owned, stream));          // x += V y, GMRES.zig:411-417
+        if (cycle_done) {
+            converged = true;
+            break;
+        }
+    }
+    st.inner_iterations += it_total;
+
+    // residual + copy-back (smooth.zig:112-153); X becomes the new frozen field
+    HIPCHK(launch_residual_copyback(X, U, n_owned, partials, stream));
+    reduce(nwg_vec);
+    HIPCHK(hipMemcpyAsync(h_red, red, sizeof(double) * MAX_PARTIALS, hipMemcpyDeviceToHost, stream));
+    sync();
+    st.last_dx2 = h_red[0];
+    st.last_dy2 = h_red[1];
+    st.last_residual = (h_red[0] + h_red[1]) * (h_red[0] + h_red[1]);   // smooth.zig:136
+    outer_done += 1;
+    return converged ? 0 : 1;
+}
+
 // Two sweeps in one pass over the interior rows: X^(k+2) = S(S(X^k)), bit-identical to two single sweeps.
 //   perimeter rows of X^(k+1)  <- perimeter-row kernel on X^k           (into M)
 //   interior rows of X^(k+2)   <- K2x2 (reads X^k and M's perimeter; leaves the first-interior ring of X^(k+1) in M)
@@ -1534,7 +1629,7 @@ void Smoother::iterate(uint64_t iterations, tm_stats* stats) {
         for (uint64_t n = 0; n < iterations; ++n) {
             if (sink) sink(g_log_ctx, 0, n, 0.0);
             if (opt.inner == TM_INNER_RELAX) relax_sweeps(1, st);
-            else st.not_converged += picard_bicgstab(st);
+            else st.not_converged += picard_solve(st);
             st.outer_iterations += 1;
             if (sink) sink(g_log_ctx, 1, n, st.last_residual);
         }
@@ -1561,7 +1656,7 @@ bool Smoother::iterate_until_update(uint64_t max_iterations, double tol, tm_stat
             st.outer_iterations += n;
         } else {
             if (sink) sink(g_log_ctx, 0, st.outer_iterations, 0.0);
-            st.not_converged += picard_bicgstab(st);
+            st.not_converged += picard_solve(st);
             if (sink) sink(g_log_ctx, 1, st.outer_iterations, st.last_residual);
             st.outer_iterations += 1;
         }
@@ -1600,7 +1695,7 @@ bool Smoother::iterate_until(uint64_t max_iterations, double tol, tm_stats* stat
             while (true) {
                 const tm_log_fn sink = g_log_sink;
                 if (sink) sink(g_log_ctx, 0, st.outer_iterations, 0.0);
-                const int rc = picard_bicgstab(st);
+                const int rc = picard_solve(st);
                 if (rc == 2) {
                     reached = true;
                     break;

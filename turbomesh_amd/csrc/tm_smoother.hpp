@@ -202,8 +202,15 @@ struct Smoother {
     void sync();
     void ensure_tmp();
 
+    // GMRES(30) (TM_INNER_GMRES; csrc/tm_gmres.hip): the m + 1 basis vectors, the device-resident Hessenberg / rotation state, a pinned copy
+    double2* gm_V = nullptr;
+    GmresScalars* gm_S = nullptr;
+    GmresScalars* h_gm = nullptr;
+
    private:
     int picard_bicgstab(tm_stats& st);
+    int picard_gmres(tm_stats& st);
+    int picard_solve(tm_stats& st) { return opt.inner == TM_INNER_GMRES ? picard_gmres(st) : picard_bicgstab(st); }
     void relax_sweeps(uint64_t n, tm_stats& st);
     void relax_pair(bool want_partials);
     std::vector<int> relax3_rows_of_owned_blocks() const;

@@ -33,6 +33,7 @@ class Inner(enum.IntEnum):
     bicgstab = _capi.TM_INNER_BICGSTAB   # Picard + matrix-free BiCGStab on D^-1 A
     relax = _capi.TM_INNER_RELAX         # one fused Jacobi elliptic sweep per outer iteration
     mg_bicgstab = _capi.TM_INNER_MG_BICGSTAB   # bicgstab, right-preconditioned by one multigrid V-cycle per block
+    gmres = _capi.TM_INNER_GMRES         # Picard + restarted GMRES(30), diagonal left preconditioner (GMRES.zig:300-423 on the device)
     auto = _capi.TM_INNER_AUTO           # mg_bicgstab when the largest block has >= 100 000 nodes, bicgstab below (decided at create)
 
 
@@ -55,6 +56,22 @@ class Option:
     @classmethod
     def hip(cls, **kw):
         return cls(tag=Tag.hip, **kw)
+
+    def served_by_hip(self):
+        """The hip option that honours this one -- what `--hip file` of the front end does with the solver an input file names:
+        gmres -> Inner.gmres (GMRES(30) on the device), bicgstab -> Inner.bicgstab, the direct backends (umfpack, petsc: exact solves,
+        umfpack.zig:18-24) -> Inner.auto with the library's tight default tolerance.  The reference's ILU(0) preconditioner
+        (BiCGStab.zig:178-277) is a sequential recurrence with no device counterpart: the diagonal takes its place (a preconditioner
+        changes the route, not the Picard iterate).  Returns (option, note or None)."""
+        if self.tag == Tag.hip:
+            return self, None
+        inner = {Tag.gmres: Inner.gmres, Tag.bicgstab: Inner.bicgstab}.get(self.tag, Inner.auto)
+        note = None
+        if self.tag in (Tag.gmres, Tag.bicgstab) and self.preconditioner == Preconditioner.ilu0:
+            note = "preconditioner ilu0 has no device counterpart: diagonal scaling is used (same Picard iterates, more inner iterations)"
+        elif self.tag not in (Tag.gmres, Tag.bicgstab):
+            note = f"direct solver `{self.tag.name}` is served by the iterative device solve at its tight default tolerance"
+        return Option.hip(inner=inner), note
 
     def c_struct(self):
         return _capi.tm_solver_opt(int(self.tag), int(self.inner), self.rtol, self.atol, self.max_inner, self.check_every,
