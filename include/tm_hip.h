@@ -149,7 +149,7 @@ enum {
 typedef struct tm_solver_opt {
     int32_t tag;             /* TM_SOLVER_* */
     int32_t inner;           /* TM_INNER_* */
-    double rtol;             /* stop the inner solve at ||D^-1(b-Ax)||_2 <= max(atol, rtol*||D^-1 b||_2); 0 -> size-aware default: 7.5e-9 / nodes clamped to [1e-16, 1e-14] (1e-14 up to 866^2 nodes; the error of the solve is conditioning x residual and the conditioning grows with the mesh) */
+    double rtol;             /* stop the inner solve at ||D^-1(b-Ax)||_2 <= max(atol, rtol*||D^-1 b||_2); 0 -> size-aware default: 7.5e-9 / nodes clamped to [1e-16, 1e-14] (1e-14 up to 866^2 nodes; the error of the solve is conditioning x residual and the conditioning grows with the mesh); 1e-14 at every size with the multigrid preconditioner, which makes the conditioning O(1) */
     double atol;             /* 0 -> 0 */
     uint64_t max_inner;      /* BiCGStab iteration cap per Picard solve; 0 -> max(10000, 12 sqrt(nodes)) (the reference caps at 1000, BiCGStab.zig:19, with its far looser stop test) */
     uint32_t check_every;    /* host convergence poll interval in inner iterations; 0 -> 8 (1 with the multigrid preconditioner) */
@@ -201,7 +201,9 @@ int tm_smooth_mesh(const tm_mesh_desc* mesh, uint64_t iterations, const tm_solve
  * differ in the two entries of every sliding row (system.fillXSpecific / fillYSpecific, smooth.zig:1115-1165): pass the
  * values after fillXSpecific as Ax_x and a copy taken after fillYSpecific as Ax_y (NULL = same values for both; exact
  * whenever the mesh has no inlet / outlet condition).  Both components are solved together on the device by BiCGStab
- * on D^-1 A with the stop test of tm_solver_opt (rtol, atol, max_inner, check_every; opt may be NULL = defaults).
+ * on D^-1 A with the stop test of tm_solver_opt (rtol, atol, max_inner, check_every; opt may be NULL = defaults; rtol 0 -> 1e-14 here at
+ * every size: the size-aware default belongs to the matrix-free path's own operator).  A recurrence residual that fails to halve over
+ * max(4000, 4 sqrt(n)) iterations ends the solve as not converged.
  * Returns TM_OK, TM_W_NOT_CONVERGED (warning, like BiCGStab.zig:368-369) or a negative error; host pointers throughout;
  * the matrix is uploaded per call -- this is the faithful "reference-assembled, GPU-solved" mode, not the fast path
  * (that is seam 1, which never assembles a matrix). */

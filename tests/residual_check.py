@@ -33,12 +33,15 @@ def assemble(x0_blocks):
     return p, i, v, b
 
 
-def scaled_residual(p, i, v, b, x, dtype=np.longdouble, chunk_rows=1 << 20):
+def scaled_residual(p, i, v, b, x, dtype=np.longdouble, chunk_rows=1 << 20, floor=None):
     """(|| D^-1 (b - A x) ||_2, || D^-1 b ||_2) per component, evaluated in `dtype`; x, b are (n, 2).  Rows are visited in chunks so that the
-    temporaries stay at ~ chunk_rows x 9 extended-precision numbers."""
+    temporaries stay at ~ chunk_rows x 9 extended-precision numbers.  floor (a 2-vector, optional) receives || D^-1 |A| |x| ||_2 per
+    component: times the unit roundoff it is the residual a vector picks up from merely being STORED in fp64 (each x_k off by up to
+    eps |x_k|), i.e. what no fp64 solver can get under."""
     n = len(p) - 1
     num = np.zeros(2, dtype=dtype)
     den = np.zeros(2, dtype=dtype)
+    flo = np.zeros(2, dtype=dtype)
     xw = x.astype(dtype)
     for r0 in range(0, n, chunk_rows):
         r1 = min(n, r0 + chunk_rows)
@@ -58,11 +61,22 @@ def scaled_residual(p, i, v, b, x, dtype=np.longdouble, chunk_rows=1 << 20):
             num[c] += np.dot(res, res)
             sb = b[r0:r1, c].astype(dtype) / diag
             den[c] += np.dot(sb, sb)
+            if floor is not None:
+                aa = np.add.reduceat(np.abs(vals) * np.abs(xw[cols, c]), starts) / np.abs(diag)
+                flo[c] += np.dot(aa, aa)
+    if floor is not None:
+        floor[:] = np.sqrt(flo).astype(np.float64)
     return np.sqrt(num), np.sqrt(den)
 
 
-def relative_residual(p, i, v, b, x1, dtype=np.longdouble):
-    """The library's own stop quantity, components together: sqrt(sum_c ||D^-1 r_c||^2) / sqrt(sum_c ||D^-1 b_c||^2), and per component."""
-    num, den = scaled_residual(p, i, v, b, x1, dtype)
-    both = float(np.sqrt((num ** 2).sum()) / np.sqrt((den ** 2).sum()))
-    return both, [float(num[c] / den[c]) for c in range(2)]
+def relative_residual(p, i, v, b, x1, dtype=np.longdouble, with_floor=False):
+    """The library's own stop quantity, components together: sqrt(sum_c ||D^-1 r_c||^2) / sqrt(sum_c ||D^-1 b_c||^2), and per component.
+    with_floor: a third value, the fp64 storage floor of that quantity: 2^-53 sqrt(sum_c ||D^-1 |A| |x_c|||^2) / the same denominator."""
+    flo = np.zeros(2) if with_floor else None
+    num, den = scaled_residual(p, i, v, b, x1, dtype, floor=flo)
+    d = np.sqrt((den ** 2).sum())
+    both = float(np.sqrt((num ** 2).sum()) / d)
+    per = [float(num[c] / den[c]) for c in range(2)]
+    if with_floor:
+        return both, per, float(2.0 ** -53 * np.sqrt((flo ** 2).sum()) / float(d))
+    return both, per

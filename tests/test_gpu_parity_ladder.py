@@ -126,6 +126,64 @@ def test_4096_two_routes_to_the_same_picard_iterates():
     rms = _rms(mg_its[0], out[solver.Inner.bicgstab][0][0])
     log_parity("ladder_block4096_mg_vs_bicgstab_default_options_rms", rms)
     assert rms <= TOL_RMS, rms
+    # ... and against something that shares NO code with the device: the reference's system at X^0 assembled by the faithful oracle on the host
+    # (smooth.zig:309-385, 923-1113 restated: CSR + right-hand sides, 151 M non-zeros), the TRUE scaled residual of each route's X^1 formed
+    # in 80-bit arithmetic (tests/residual_check.py).  No fp64 vector can read below the storage floor 2^-53 ||D^-1 |A| |x||| / ||D^-1 b||
+    # (6e-15 here -- above the 4.5e-16 the recurrence residual is driven to): the multigrid route sits ON it, the diagonal-only route stalls
+    # ~40 x above it (its remaining error is low-frequency: little residual, and the part that the tight recurrence tolerance keeps removing).
+    from tests import residual_check as rc
+
+    p, ci, v, b = rc.assemble([x0])
+    assert len(p) - 1 == n * n
+    for inner, bound in ((solver.Inner.mg_bicgstab, 4.0), (solver.Inner.bicgstab, 200.0)):
+        x1 = out[inner][0][0].reshape(-1, 2)
+        both, per, floor = rc.relative_residual(p, ci, v, b, x1, with_floor=True)
+        log_parity(f"block4096_{inner.name}_true_scaled_residual_vs_oracle_assembled_system", both)
+        log_parity(f"block4096_{inner.name}_true_scaled_residual_over_fp64_storage_floor", both / floor)
+        print(f"[4096] {inner.name}: true scaled residual vs the oracle-assembled system {both:.2e} = {both / floor:.1f} x the fp64 storage floor {floor:.2e}")
+        assert both <= bound * floor and both <= 1e-12, (inner.name, both, floor)
+
+
+def test_1025_three_routes_one_of_them_through_the_oracle_assembled_csr():
+    # the same statement with a THIRD route that shares no operator kernel with the other two: the oracle's CSR itself solved on the device
+    # through seam 2 (tm_csr_solve: the CSR mat-vec of csrc/tm_csr.hip on the reference-order coefficients) from the same initial guess.
+    # All three X^1 within 1e-10 rms of one another and every true residual within a small multiple of the storage floor.
+    # (4096^2: tools/oracle_residual.py 4096 --csr, 102 s for the CSR route -- profiles/r04_parity_rms.txt: 4.9e-12 / 1.4e-11.)
+    import ctypes as C
+
+    from tests import residual_check as rc
+    from turbomesh_amd import _capi
+
+    n = 1025
+    x0 = configs.single_block(n, n, perturb=0.25).blocks[0].points.data.copy()
+    its = {}
+    for inner in (solver.Inner.mg_bicgstab, solver.Inner.bicgstab, solver.Inner.gmres):
+        m = configs.single_block(n, n, perturb=0.25)
+        with smooth.Smoother(m, solver.Option.hip(inner=inner, max_inner=200000)) as sm:
+            st = sm.iterate(1)
+            sm.download()
+        assert st["not_converged"] == 0, (inner.name, st)
+        its[inner.name] = m.blocks[0].points.data.reshape(-1, 2).copy()
+    p, ci, v, b = rc.assemble([x0])
+    xs, ys = np.ascontiguousarray(x0.reshape(-1, 2)[:, 0]).copy(), np.ascontiguousarray(x0.reshape(-1, 2)[:, 1]).copy()
+    bx, by = np.ascontiguousarray(b[:, 0]), np.ascontiguousarray(b[:, 1])
+    opt = solver.Option.hip(rtol=7.5e-9 / (n * n), max_inner=200000).c_struct()   # the matrix-free path's size-aware default, spelled out (seam 2 defaults to 1e-14)
+    st = _capi.tm_stats()
+    ip = C.POINTER(C.c_int32)
+    rcode = _capi.lib().tm_csr_solve(len(p) - 1, p.ctypes.data_as(ip), ci.ctypes.data_as(ip), _capi.f64ptr(v), None, _capi.f64ptr(bx), _capi.f64ptr(by),
+                                     _capi.f64ptr(xs), _capi.f64ptr(ys), C.byref(opt), C.byref(st))
+    assert rcode == 0, rcode
+    its["csr_seam2"] = np.stack([xs, ys], axis=1)
+    names = list(its)
+    for a in range(len(names)):
+        for c in range(a + 1, len(names)):
+            d = _rms(its[names[a]], its[names[c]])
+            log_parity(f"block1025_{names[a]}_vs_{names[c]}_rms", d)
+            assert d <= TOL_RMS, (names[a], names[c], d)
+    for name, x1 in its.items():
+        both, _, floor = rc.relative_residual(p, ci, v, b, x1, with_floor=True)
+        log_parity(f"block1025_{name}_true_scaled_residual_over_fp64_storage_floor", both / floor)
+        assert both <= 200.0 * floor, (name, both, floor)
 
 
 def test_1025_both_routes_reach_the_same_fixed_point():

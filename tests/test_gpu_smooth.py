@@ -298,3 +298,47 @@ def test_default_tolerance_meets_the_parity_bar_on_stretched_cells():
             ref = np.concatenate([b.reshape(-1, 2) for b in iterates[it]], axis=0)
             rms = float(np.sqrt(np.mean((mesh_flat(mesh) - ref) ** 2)))
             assert st["not_converged"] == 0 and rms <= 1e-10, (it, rms)
+
+
+def test_overlapping_strip_layout_of_the_krylov_kernels_agrees_with_the_halo_layout():
+    # TM_VK_OVERLAP: the two kernels of the two-kernel BiCGStab iteration on 62-column overlapping strips (no halo columns loaded; the
+    # default between 1.5 and 12 million nodes per process) against the 64-column tiling with halo loads.  Same arithmetic per node; the
+    # partial sums are grouped by other tiles, so the Krylov scalars differ in their last bits: three iterations agree to 1e-13, Picard
+    # iterates at the default tolerance to well under the parity bar, on shapes around the strip edges (62 / 124 / 248 owned columns).
+    import json
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    child = r"""
+import json, sys
+import numpy as np
+from turbomesh_amd import configs
+from turbomesh_amd.smoothing import smooth, solver, wall_control_function as wcf
+out = {}
+flat = lambda m: np.concatenate([b.points.data.ravel() for b in m.blocks])
+cases = [(f"{ni}x{nj}", (lambda ni=ni, nj=nj: configs.single_block(ni, nj, perturb=0.2)), None) for ni, nj in ((40, 64), (33, 65), (50, 125), (37, 126), (31, 127), (45, 250), (64, 251), (70, 700))]
+cases.append(("strip3", lambda: configs.strip(3, 40, 130, reverse_odd=True), None))
+cases.append(("plate_white", lambda: configs.plate(15, 9), wcf.Algorithm(wcf.White(0.02))))
+for name, build, cf in cases:
+    m = build()
+    smooth.mesh(m, 1, solver.Option.hip(max_inner=3, check_every=3), cf)
+    short = flat(m)
+    m = build()
+    st = smooth.mesh(m, 2, solver.Option.hip(), cf)
+    out[name] = {"after3": short.tolist(), "solved": flat(m).tolist(), "nc": st["not_converged"]}
+print(json.dumps(out))
+"""
+    res = {}
+    for ov in ("0", "1"):
+        env = dict(os.environ, TM_VK_OVERLAP=ov, PYTHONPATH=root + os.pathsep + os.environ.get("PYTHONPATH", ""))
+        r = subprocess.run([sys.executable, "-c", child], capture_output=True, text=True, timeout=600, cwd=root, env=env)
+        assert r.returncode == 0, r.stderr[-3000:]
+        res[ov] = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    for name in res["0"]:
+        a, b = res["0"][name], res["1"][name]
+        assert a["nc"] == 0 and b["nc"] == 0
+        assert np.abs(np.array(a["after3"]) - np.array(b["after3"])).max() <= 1e-13, name
+        # two roundings of the same solve sit conditioning x tolerance apart: 2.7e-11 on the stretched 70 x 700 block, 1e-12 on the others
+        assert _rms(np.array(a["solved"]), np.array(b["solved"])) <= 0.5 * TOL_RMS, (name, _rms(np.array(a["solved"]), np.array(b["solved"])))

@@ -20,6 +20,9 @@ def test_exact_iterate_has_a_rounding_level_residual_and_a_perturbed_one_does_no
     assert both < 1e-14 and max(per) < 1e-14, (both, per)              # the exact solve in fp64: a few eps (1.5e-15 here)
     both64, _ = rc.relative_residual(p, i, v, b, x1, dtype=np.float64)
     assert both64 < 2e-14
+    # the storage floor: what a vector picks up from being rounded to fp64 -- the exact solve sits within a small factor of it
+    _, _, floor = rc.relative_residual(p, i, v, b, x1, with_floor=True)
+    assert 1e-17 < floor < 1e-15 and both < 20 * floor, (both, floor)
     # chunking does not change the figure
     n1, d1 = rc.scaled_residual(p, i, v, b, x1, chunk_rows=1000)
     n2, d2 = rc.scaled_residual(p, i, v, b, x1, chunk_rows=1 << 20)

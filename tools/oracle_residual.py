@@ -59,7 +59,7 @@ def main():
         x = x0.reshape(-1, 2)
         xs, ys = np.ascontiguousarray(x[:, 0]).copy(), np.ascontiguousarray(x[:, 1]).copy()
         bx, by = np.ascontiguousarray(b[:, 0]), np.ascontiguousarray(b[:, 1])
-        opt = solver.Option.hip().c_struct()
+        opt = solver.Option.hip(rtol=rtol_default, max_inner=400000).c_struct()   # the matrix-free path's size-aware default spelled out (seam 2 itself defaults to 1e-14)
         st = _capi.tm_stats()
         ip = C.POINTER(C.c_int32)
         t0 = time.perf_counter()
@@ -73,12 +73,14 @@ def main():
     worst = 0.0
     for name, x1 in iterates.items():
         t0 = time.perf_counter()
-        both, per = rc.relative_residual(p, i, v, b, x1)
+        both, per, floor = rc.relative_residual(p, i, v, b, x1, with_floor=True)
         both64, _ = rc.relative_residual(p, i, v, b, x1, dtype=np.float64)
         worst = max(worst, both)
-        say(f"true scaled residual of X^1 [{name:12s}] vs the oracle-assembled system: {both:.3e} (x {per[0]:.3e}, y {per[1]:.3e}); the same evaluated in fp64: {both64:.3e}   ({time.perf_counter() - t0:.0f} s)")
+        say(f"true scaled residual of X^1 [{name:12s}] vs the oracle-assembled system: {both:.3e} (x {per[0]:.3e}, y {per[1]:.3e}) = {both / floor:5.1f} x the fp64 storage floor "
+            f"2^-53 ||D^-1 |A| |x||| / ||D^-1 b|| = {floor:.2e}; evaluated in fp64: {both64:.3e}   ({time.perf_counter() - t0:.0f} s)")
     both0, _ = rc.relative_residual(p, i, v, b, x0.reshape(-1, 2))
-    say(f"for scale: X^0 itself {both0:.3e}; a residual EVALUATED in fp64 cannot read below ~ eps sqrt(rows) |x| / ||D^-1 b||")
+    say(f"for scale: X^0 itself {both0:.3e}; the recurrence residual the library stops on ({rtol_default:.1e} relative) lies BELOW the storage floor: the true residual of any fp64 "
+        "vector cannot, and the diagonal-only solve stalls ~40 x above it while its low-frequency error -- which carries the distance from the exact iterate but little residual -- keeps falling")
     names = list(iterates)
     for a in range(len(names)):
         for c in range(a + 1, len(names)):

@@ -143,7 +143,9 @@ extern "C" int tm_csr_solve(uint64_t n64, const int32_t* Ap, const int32_t* Ai, 
         tm_solver_opt opt;
         std::memset(&opt, 0, sizeof(opt));
         if (opt_in) opt = *opt_in;
-        if (!(opt.rtol > 0)) opt.rtol = default_rtol(static_cast<double>(n));
+        // 1e-14 at every size: the size-aware default of the matrix-free path belongs to ITS operator (the frozen Winslow system, whose
+        // conditioning grows with the node count); this entry point takes any matrix the caller assembled
+        if (!(opt.rtol > 0)) opt.rtol = 1e-14;
         if (!(opt.atol > 0)) opt.atol = 0.0;
         if (opt.max_inner == 0) opt.max_inner = default_max_inner(static_cast<double>(n));
         if (opt.check_every == 0) opt.check_every = 8;
@@ -232,8 +234,13 @@ extern "C" int tm_csr_solve(uint64_t n64, const int32_t* Ap, const int32_t* Ai, 
         };
         uint64_t it_total = 0;
         int restarts = 0;
-        bool converged = false;
+        bool converged = false, stalled = false;
         double rr0[2] = {0.0, 0.0};
+        // stagnation watch, as in Smoother::poll_done: a recurrence residual that fails to halve over max(4000, 4 sqrt(n)) iterations ends
+        // the solve (not converged, a warning) instead of running to the iteration cap
+        double stall_best[2] = {0.0, 0.0};
+        uint64_t stall_since = 0;
+        const uint64_t stall_window = std::max<uint64_t>(4000, static_cast<uint64_t>(4.0 * std::sqrt(static_cast<double>(n))));
         while (true) {
             hipLaunchKernelGGL((k_csr_apply<true, DOT_OUT2>), dim3(nwg), dim3(256), 0, st, A, u, d_b.as<double2>(), nullptr, r, partials);
             HIPCHK(hipGetLastError());
@@ -272,9 +279,20 @@ extern "C" int tm_csr_solve(uint64_t n64, const int32_t* Ap, const int32_t* Ai, 
                         breakdown = !converged;
                         break;
                     }
+                    bool progress = false;
+                    for (int c = 0; c < 2; ++c)
+                        if (!h_S.done[c] && (!(stall_best[c] > 0.0) || h_S.rr[c] < 0.25 * stall_best[c])) {
+                            stall_best[c] = h_S.rr[c];
+                            progress = true;
+                        }
+                    if (progress) stall_since = it_total;
+                    else if (it_total - stall_since > stall_window) {
+                        stalled = true;
+                        break;
+                    }
                 }
             }
-            if (converged || !breakdown || restarts >= 8 || it_total >= opt.max_inner) break;
+            if (converged || !breakdown || stalled || restarts >= 8 || it_total >= opt.max_inner) break;
             restarts += 1;   // rho or omega vanished: restart from the current iterate (the reference only warns, BiCGStab.zig:368-369)
         }
         hipLaunchKernelGGL(k_deinterleave, dim3(nwg), dim3(256), 0, st, n, u, tmp, tmp + n);

@@ -62,6 +62,7 @@ struct ApplyBlock {
 };
 // number of workgroups k2 launches for a block (also the number of partial rows it writes)
 int apply_block_nwg(int ni, int nj, int rows = 0);
+int apply_block_nwg_overlap(int ni, int nj, int rows = 0);   // the same for the overlapping-strip layout of the large-mesh Krylov kernels
 void tune_apply(int rows_per_chunk, int unroll, int pipe, int nt);   // <=0 (pipe, nt: <0) keeps the current value
 hipError_t launch_apply_block(const ApplyBlock& a, int mode, int dot, hipStream_t stream);
 // several blocks of one rank in one launch (per group of APPLY_BATCH_MAX); block k's partial sums go to blocks[k].partials
@@ -190,8 +191,10 @@ struct VirtualIn {
     double2* rout = nullptr;
     double2* uio = nullptr;
 };
+// overlap: the 62-column overlapping-strip layout (VK_R / VK_S2 only; apply_tile<.., OV>): blocks[k].partials must then leave room for
+// apply_block_nwg_overlap(ni, nj, rows) rows per block
 hipError_t launch_apply_virtual(const ApplyBlock* blocks, int n, const EdgeRowsDev& e, const VirtualIn& V, const double2* xk, const double2* pq, double2* out,
-                                double* edge_partials, const LazyScalars& scal, hipStream_t stream);
+                                double* edge_partials, const LazyScalars& scal, hipStream_t stream, bool overlap = false);
 // b (unscaled) per perimeter row scattered into a dense vector that was zeroed by the caller; scaled!=0 writes D^-1 b
 hipError_t launch_edge_rhs(const EdgeRowsDev& e, const double2* xk, const double2* pq, double2* rhs_out, int scaled,
                            double* partials /* [nwg*MAX_PARTIALS]: sum (D^-1 b)^2 x,y */, hipStream_t stream);

@@ -267,6 +267,9 @@ static int g_rows_per_chunk = 18;   // tunable (tm_tune_apply); short chunks: se
 static int g_unroll = 6;   // rows per load group: 3 or 6
 static int g_nt = 1;
 
+constexpr unsigned OOB_VOFFSET = 0x80000000u;   // beyond num_records of every buffer resource below: the hardware drops the lane's store
+typedef int v4i32 __attribute__((ext_vector_type(4)));
+
 typedef double d2v __attribute__((ext_vector_type(2)));
 // streaming store of a double2 (the vectors are far larger than the caches; worth +25 % on a copy of this footprint)
 __device__ __forceinline__ void store_nt(double2* dst, double2 v) {
@@ -304,7 +307,11 @@ __device__ __forceinline__ double2 load_nt(const double2* src);   // defined wit
 //   VK_P: in + va * (in2 - vb * in3)   (p = r + beta (p - omega v), stored to a.pout for the owned rows)
 //   VK_R: virtual_r(in, in2, in3, in4) (va, vb, vc = alpha, omega, beta): r', p' and the solution update stored for the owned rows
 //         as each row ENTERS the window (a row enters once per workgroup; the chunk's two halo rows belong to the neighbours)
-template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool NT, int VK = VK_NONE>
+// OV (overlapping strips, the Krylov kernels of large meshes): a wave holds the 64 columns 62 s .. 62 s + 63 of strip s and OWNS the 62 in
+// the middle (lanes 1 .. 62), so both j-neighbours of every owned column sit in the wave and no halo column is ever loaded -- with seven
+// input streams (VK_R) the halo values of a six-row load group were 120 of the kernel's ~290 registers.  3 % of the columns are loaded
+// twice (mostly from L2).  Same arithmetic per node, same bits.
+template <int MODE, int DOT, bool FIELD, bool HAS_PQ, int U, bool NT, int VK = VK_NONE, bool OV = false>
 __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG, int nRC, int bid, double2 va = make_double2(0.0, 0.0),
                                            double2 vb = make_double2(0.0, 0.0), double2 vc = make_double2(0.0, 0.0)) {
     static_assert(U % 3 == 0, "the 3-row window rotates by renaming: the row group must be a multiple of 3");
@@ -319,19 +326,20 @@ __device__ __forceinline__ void apply_tile(const ApplyBlock& a, int RI, int nSG,
     const int sg = logical - rc * nSG;
 
     const int ni = a.ni, nj = a.nj;
-    const int j0 = (sg * 4 + wave) * 64;
+    const int j0 = (sg * 4 + wave) * (OV ? 62 : 64);   // OV: the wave's first LOADED column (lane 0); its first owned column is j0 + 1
     const int j = j0 + lane;
     const int jc = min(j, nj - 1);
-    const bool edge_lane = (lane == 0) || (lane == 63);
+    const bool edge_lane = !OV && ((lane == 0) || (lane == 63));
     const int hcol = (lane == 0) ? max(j0 - 1, 0) : min(j0 + 64, nj - 1);
-    const bool valid_col = (j >= 1) && (j <= nj - 2);
-    const bool full_wave = (j0 >= 1) && (j0 + 63 <= nj - 2);   // wave-uniform: every lane owns an output column
+    const bool valid_col = (j >= 1) && (j <= nj - 2) && (!OV || (lane >= 1 && lane <= 62));
+    // wave-uniform: every lane owns an output column (never with OV: its two halo lanes store nothing, so it takes the predicated path --
+    // masking them by out-of-range buffer-store offsets instead, as K2x2 does, measured SLOWER here: 4096^2 914 against 876 us per iteration)
+    const bool full_wave = !OV && (j0 >= 1) && (j0 + 63 <= nj - 2);
     const int i0 = 1 + rc * RI;
     const int i1 = min(i0 + RI, ni - 1);   // output rows [i0, i1)
 
     double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
-
-    if (j0 < nj && i0 < i1) {   // wave-uniform
+    if ((OV ? (j0 + 1 <= nj - 2) : (j0 < nj)) && i0 < i1) {   // wave-uniform
         auto load_row = [&](const double2* __restrict__ v, int row, double2& c, double2& h) {
             const double2* rp = v + static_cast<size_t>(row) * nj;
             c = rp[jc];
@@ -627,9 +635,6 @@ struct Relax2Tile {
 #ifndef TM_R2_SAUX
 #define TM_R2_SAUX 2   // cache policy of K2x2's result stores: 2 = nt (streaming); experiment builds override it (tools/dev/ab_saux.sh)
 #endif
-constexpr unsigned OOB_VOFFSET = 0x80000000u;   // beyond num_records of every buffer resource below: the hardware drops the lane's store
-
-typedef int v4i32 __attribute__((ext_vector_type(4)));
 // A row in window form: value, e = right - left, h = right + left (zero-fill shifts: lanes 0 / 63 hold garbage there)
 struct Row3 {
     double2 c, e, h;
@@ -1567,6 +1572,13 @@ int apply_block_nwg(int ni, int nj, int rows) {
     const int nRC = (ni - 2 + RI - 1) / RI;
     return nSG * nRC;
 }
+// strip groups (4 waves each) of the overlapping-strip layout: 62 owned columns per wave over the interior columns 1 .. nj-2
+static inline int overlap_strip_groups(int nj) { return ((nj - 2 + 61) / 62 + 3) / 4; }
+int apply_block_nwg_overlap(int ni, int nj, int rows) {
+    const int RI = rows_per_chunk(ni, nj, rows);
+    const int nRC = (ni - 2 + RI - 1) / RI;
+    return overlap_strip_groups(nj) * nRC;
+}
 
 template <int MODE, int DOT, bool FIELD, bool HAS_PQ>
 static hipError_t launch_apply_u(const ApplyBlock& a, int RI, int nSG, int nRC, hipStream_t st) {
@@ -1908,7 +1920,7 @@ struct VirtualDot {
 // spills 37-70 of them to scratch, which a small mesh (one round of workgroups, more of them than CUs) prefers to waiting for a
 // second round (T106: 28.0 against 29.7 us per iteration); a large mesh prefers no spills (4096^2: 874 against 890 us), and so does
 // a launch of at most one workgroup per CU (a 256^2 block: 20.7 against 22.1 us).
-template <bool HAS_PQ, int VK, int MINW>
+template <bool HAS_PQ, int VK, int MINW, bool OV = false>
 __global__ __launch_bounds__(256, MINW) void k_apply_vk(ApplyBatch B, int total_interior, EdgeRowsDev e, VirtualIn V, const double2* __restrict__ xk,
                                                   const double2* __restrict__ pq, double2* __restrict__ out, double* edge_partials, LazyScalars L) {
     constexpr int DOT = VirtualDot<VK>::value;
@@ -1919,7 +1931,7 @@ __global__ __launch_bounds__(256, MINW) void k_apply_vk(ApplyBatch B, int total_
 #pragma unroll
         for (int q = 1; q < APPLY_BATCH_MAX; ++q)
             if (q < B.n && static_cast<int>(blockIdx.x) >= B.start[q]) k = q;
-        apply_tile<MODE_SCALED, DOT, false, HAS_PQ, 3, true, VK>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], static_cast<int>(blockIdx.x) - B.start[k], A.va, A.vb, A.vc);
+        apply_tile<MODE_SCALED, DOT, false, HAS_PQ, 3, true, VK, OV>(B.b[k], B.RI[k], B.nSG[k], B.nRC[k], static_cast<int>(blockIdx.x) - B.start[k], A.va, A.vb, A.vc);
         return;
     }
     const int wg = static_cast<int>(blockIdx.x) - total_interior;
@@ -1997,7 +2009,8 @@ hipError_t launch_apply_edge_blocks(const ApplyBlock* blocks, int n, int mode, i
 }
 
 hipError_t launch_apply_virtual(const ApplyBlock* blocks, int n, const EdgeRowsDev& e, const VirtualIn& V, const double2* xk, const double2* pq, double2* out,
-                                double* edge_partials, const LazyScalars& scal, hipStream_t st) {
+                                double* edge_partials, const LazyScalars& scal, hipStream_t st, bool overlap) {
+    if (overlap && V.kind != VK_R && V.kind != VK_S2) return hipErrorInvalidValue;   // the two kernels of the two-kernel iteration
     if (e.nrows == 0 || V.kind < VK_S || V.kind > VK_S2) return hipErrorInvalidValue;
     const bool has_pq = pq != nullptr;
     const bool merged = n <= APPLY_BATCH_MAX;   // one launch for everything; else interior groups first, perimeter rows last
@@ -2012,7 +2025,7 @@ hipError_t launch_apply_virtual(const ApplyBlock* blocks, int n, const EdgeRowsD
             const int q = B.n++;
             B.b[q] = a;
             B.RI[q] = rows_per_chunk(a.ni, a.nj, a.rows);
-            B.nSG[q] = (a.nj + 255) / 256;
+            B.nSG[q] = overlap ? overlap_strip_groups(a.nj) : (a.nj + 255) / 256;
             B.nRC[q] = (a.ni - 2 + B.RI[q] - 1) / B.RI[q];
             B.start[q] = total;
             total += B.nSG[q] * B.nRC[q];
@@ -2021,6 +2034,15 @@ hipError_t launch_apply_virtual(const ApplyBlock* blocks, int n, const EdgeRowsD
         const dim3 grid(merged ? total + e.nwg : total), block(256);
         if (grid.x == 0) continue;
         const int ti = merged ? total : -1;
+        if (overlap) {   // 62-column strips: no halo registers, two workgroups per CU without spills
+            if (V.kind == VK_R) {
+                if (has_pq) hipLaunchKernelGGL((k_apply_vk<true, VK_R, 2, true>), grid, block, 0, st, B, ti, e, V, xk, pq, out, edge_partials, L);
+                else hipLaunchKernelGGL((k_apply_vk<false, VK_R, 2, true>), grid, block, 0, st, B, ti, e, V, xk, pq, out, edge_partials, L);
+            } else {
+                if (has_pq) hipLaunchKernelGGL((k_apply_vk<true, VK_S2, 2, true>), grid, block, 0, st, B, ti, e, V, xk, pq, out, edge_partials, L);
+                else hipLaunchKernelGGL((k_apply_vk<false, VK_S2, 2, true>), grid, block, 0, st, B, ti, e, V, xk, pq, out, edge_partials, L);
+            }
+        } else
 #define TM_VK(PQ, K) hipLaunchKernelGGL((k_apply_vk<PQ, K, 2>), grid, block, 0, st, B, ti, e, V, xk, pq, out, edge_partials, L)
 #define TM_VK1(PQ, K) hipLaunchKernelGGL((k_apply_vk<PQ, K, 1>), grid, block, 0, st, B, ti, e, V, xk, pq, out, edge_partials, L)
         if (V.kind == VK_S) {

@@ -165,7 +165,11 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
 
     topo = topology_from_desc(mesh);
     dof_global = topo.dof;
-    if (!(opt.rtol > 0)) opt.rtol = (opt.flags & TM_OPT_RTOL_INITIAL) ? 1e-2 : default_rtol(static_cast<double>(dof_global));
+    // size-aware for the diagonal-only solves (default_rtol, tm_smoother.hpp); the multigrid-preconditioned solve leaves a residual with a
+    // flat spectrum and sits on the fp64 floor of the exact iterate at EVERY size with 1e-14 (4.9e-12 rms from the
+    // 1e-16 run at 4096^2, true residual against the oracle-assembled system on the storage floor) -- tightening it buys iterations only
+    if (!(opt.rtol > 0))
+        opt.rtol = (opt.flags & TM_OPT_RTOL_INITIAL) ? 1e-2 : (opt.inner == TM_INNER_MG_BICGSTAB ? 1e-14 : default_rtol(static_cast<double>(dof_global)));
     if (opt.max_inner == 0) opt.max_inner = default_max_inner(static_cast<double>(dof_global));
     try {
         all_rows = build_rows(topo);
@@ -569,10 +573,28 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     }
     nwg_vec = vec_nwg(n_owned);
     const int nwg3_all = fuse_triples ? nwg_apply3 : (triples_coupled ? nwg_apply3 + edge_L[2].nwg : 0);
-    const uint64_t npart = static_cast<uint64_t>(std::max(std::max(std::max(nwg_apply, nwg_apply2), nwg3_all), nwg_vec)) * MAX_PARTIALS;
+    // Overlapping strips for the two kernels of the two-kernel BiCGStab iteration (single process, no preconditioner -- where fuse2 holds,
+    // below): no halo registers -> 234 instead of 276 VGPRs for VK_R, two workgroups per CU without spills.  Where it pays was MEASURED, same
+    // box, alternating runs (tools/dev/vk_overlap_sizes.py, us per iteration halo loads / overlapping strips): 1024^2 74.4 / 80.0,
+    // 1448^2 124.7 / 110.7, 2048^2 271.2 / 255.7, 2896^2 516.0 / 485.9, 4096^2 862-882 / 870-918, 5792^2 1610 / 1733 -- i.e. between
+    // ~1.5 and ~12 million nodes per process, where the seven read and four write streams of the pass still find part of their rows in the
+    // Infinity Cache; at 4096^2 and beyond the pass is bound by the HBM streams alone and the 3 % of re-read columns cost what the
+    // second workgroup per CU gives.  TM_VK_OVERLAP=0/1 forces it off / on (A/B runs, the tests on small meshes).
+    vk_overlap = !has_hooks && opt.inner == TM_INNER_BICGSTAB && !(opt.flags & TM_OPT_EAGER_SCALARS) && lp.n_owned >= 1500000 && lp.n_owned <= 12000000;
+    if (const char* e = std::getenv("TM_VK_OVERLAP")) vk_overlap = !has_hooks && opt.inner == TM_INNER_BICGSTAB && !(opt.flags & TM_OPT_EAGER_SCALARS) && std::atoi(e) != 0;
+    if (vk_overlap) {
+        int off_ov = 0;
+        for (int64_t b : lp.owned_blocks) {
+            poff_ov.push_back(off_ov);
+            off_ov += apply_block_nwg_overlap(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), apply_rows);
+        }
+        poff_edge_ov = off_ov;
+        nwg_apply_ov = off_ov + edge.nwg;
+    }
+    const uint64_t npart = static_cast<uint64_t>(std::max(std::max(std::max(std::max(nwg_apply, nwg_apply_ov), nwg_apply2), nwg3_all), nwg_vec)) * MAX_PARTIALS;
     // Krylov modes on a small single-process mesh: the scalar steps travel with the kernels that consume their result (LazyScalars,
     // tm_kernels.h) -- three partial-sum buffers in rotation, two scalar blocks
-    lazy = !has_hooks && opt.inner != TM_INNER_RELAX && std::max(nwg_apply, nwg_vec) <= 512 && !(opt.flags & TM_OPT_EAGER_SCALARS);
+    lazy = !has_hooks && opt.inner != TM_INNER_RELAX && std::max(std::max(nwg_apply, nwg_apply_ov), nwg_vec) <= 512 && !(opt.flags & TM_OPT_EAGER_SCALARS);
     // second apply of an iteration with the s-update folded in: single process (nothing of s has to travel) and no preconditioner
     // (which wants s as a stored vector)
     fuse_s = !has_hooks && opt.inner == TM_INNER_BICGSTAB && !(opt.flags & TM_OPT_EAGER_SCALARS);
@@ -897,6 +919,7 @@ void Smoother::apply(const double2* in, double2* out, int mode, int dot, const d
 void Smoother::apply_virtual(int kind, const double2* in, const double2* in2, const double2* in3, double2* pout, double2* out, const double2* in4, double2* rout,
                              double2* uio) {
     const bool dot_aux = kind == VK_P || kind == VK_R || kind == VK_S2;
+    const bool ov = vk_overlap && (kind == VK_R || kind == VK_S2);
     std::vector<ApplyBlock> blocks(lp.owned_blocks.size());
     for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
         const int64_t b = lp.owned_blocks[k];
@@ -917,7 +940,7 @@ void Smoother::apply_virtual(int kind, const double2* in, const double2* in2, co
         a.nj = static_cast<int>(topo.nj[b]);
         a.omega = 0.0;
         a.rows = apply_rows;
-        a.partials = partials + static_cast<size_t>(poff[k]) * MAX_PARTIALS;
+        a.partials = partials + static_cast<size_t>(ov ? poff_ov[k] : poff[k]) * MAX_PARTIALS;
     }
     VirtualIn V;
     V.kind = kind;
@@ -929,9 +952,9 @@ void Smoother::apply_virtual(int kind, const double2* in, const double2* in2, co
     V.pout = pout;
     V.rout = rout;
     V.uio = uio;
-    HIPCHK(launch_apply_virtual(blocks.data(), static_cast<int>(blocks.size()), edge, V, X, PQ, out, partials + static_cast<size_t>(poff_edge) * MAX_PARTIALS,
-                                scalars_for(), stream));
-    reduce_update(nwg_apply, kind == VK_P ? STEP_SIGMA : (kind == VK_S ? STEP_SS_TSTT : (kind == VK_R ? STEP_A2 : STEP_B2)));
+    HIPCHK(launch_apply_virtual(blocks.data(), static_cast<int>(blocks.size()), edge, V, X, PQ, out,
+                                partials + static_cast<size_t>(ov ? poff_edge_ov : poff_edge) * MAX_PARTIALS, scalars_for(), stream, ov));
+    reduce_update(ov ? nwg_apply_ov : nwg_apply, kind == VK_P ? STEP_SIGMA : (kind == VK_S ? STEP_SS_TSTT : (kind == VK_R ? STEP_A2 : STEP_B2)));
 }
 
 void Smoother::white_launch(int update) {
@@ -972,13 +995,33 @@ void Smoother::precondition(const double2* in, double2* out) {
 // (scalar_update_body), so its U and r no longer move and `done` never reverts.  `poll_iters` = the iteration count of the poll
 // that saw the end (what a blocking poll would have reported).
 int Smoother::poll_done(uint64_t it, bool final) {
-    auto verdict = [&](const KrylovScalars* h) { return (h->done[0] && h->done[1]) ? ((h->done[0] == 1 && h->done[1] == 1) ? 1 : 2) : 0; };
+    // Stagnation watch: the default tolerance of the diagonal-only solve lies below the TRUE residual fp64 can reach (it is met
+    // by the recurrence residual drifting down, which does keep removing low-frequency error: DESIGN.md section 5); should the recurrence
+    // residual of an active component ever fail to halve over max(4000, 4 sqrt(dof)) iterations, the solve is over -- reported as not
+    // converged (a warning), without a restart, instead of running to the iteration cap.
+    auto verdict = [&](const KrylovScalars* h, uint64_t at) {
+        if (h->done[0] && h->done[1]) return (h->done[0] == 1 && h->done[1] == 1) ? 1 : 2;
+        bool progress = false;
+        for (int c = 0; c < 2; ++c) {
+            if (h->done[c]) continue;
+            if (!(stall_best[c] > 0.0) || h->rr[c] < 0.25 * stall_best[c]) {   // ||r||^2 down by 4 = the norm halved
+                stall_best[c] = h->rr[c];
+                progress = true;
+            }
+        }
+        if (progress) stall_since = at;
+        else if (at > stall_since && at - stall_since > stall_window) {
+            stalled = true;
+            return 2;
+        }
+        return 0;
+    };
     flush_pending();
     if (!pipelined_poll) {
         HIPCHK(hipMemcpyAsync(h_S, S, sizeof(KrylovScalars), hipMemcpyDeviceToHost, stream));
         sync();
         poll_iters = it;
-        return verdict(h_S);
+        return verdict(h_S, it);
     }
     int v = 0;
     const int cur = poll_slot, prev = poll_slot ^ 1;
@@ -986,12 +1029,12 @@ int Smoother::poll_done(uint64_t it, bool final) {
     HIPCHK(hipEventRecord(ev_poll[cur], stream));
     if (poll_open) {
         HIPCHK(hipEventSynchronize(ev_poll[prev]));
-        v = verdict(h_poll[prev]);
+        v = verdict(h_poll[prev], poll_it[prev]);
         if (v) poll_iters = poll_it[prev];
     }
     if (!v && final) {
         HIPCHK(hipEventSynchronize(ev_poll[cur]));
-        v = verdict(h_poll[cur]);
+        v = verdict(h_poll[cur], it);
         poll_iters = it;
     }
     poll_it[cur] = it;
@@ -1018,6 +1061,10 @@ int Smoother::picard_bicgstab(tm_stats& st) {
     uint64_t it_total = 0;
     bool converged = false;
     poll_iters = 0;
+    stall_best[0] = stall_best[1] = 0.0;
+    stall_since = 0;
+    stalled = false;
+    stall_window = std::max<uint64_t>(4000, static_cast<uint64_t>(4.0 * std::sqrt(static_cast<double>(dof_global))));
     while (true) {
         // r = D^-1 (b - A U) ; r_hat = r ; p = v = 0   (first pass: U is X)
         apply(restarts == 0 ? X : U, r, MODE_RESID, DOT_OUT2, nullptr, X, 0.0, fuse2 ? STEP_INIT2 : STEP_INIT);
@@ -1127,7 +1174,7 @@ int Smoother::picard_bicgstab(tm_stats& st) {
             flush_pending();
             HIPCHK(launch_xr_update_vs(scalars_for(), U, p, v, t, r, r_hat, n_owned, partials, stream));   // its partial sums are not used
         }
-        if (converged || !breakdown || restarts >= 8 || it_total >= opt.max_inner) break;
+        if (converged || !breakdown || stalled || restarts >= 8 || it_total >= opt.max_inner) break;
         restarts += 1;   // breakdown (rho or omega vanished): restart from the current iterate
     }
     st.inner_iterations += (converged && poll_iters) ? poll_iters : it_total;

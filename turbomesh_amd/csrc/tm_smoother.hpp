@@ -102,7 +102,15 @@ struct Smoother {
     uint64_t poll_it[2] = {0, 0}, poll_iters = 0;
     int poll_slot = 0;
     int poll_done(uint64_t it, bool final);
+    double stall_best[2] = {0.0, 0.0};   // stagnation watch of the inner solve (poll_done): best ||r||^2 per component, iteration of the last halving
+    uint64_t stall_since = 0, stall_window = 4000;
+    bool stalled = false;
     double* h_red = nullptr;        // pinned
+    // the two-kernel Krylov iteration of a large mesh runs its kernels on overlapping 62-column strips (apply_tile<.., OV>): their own
+    // partial-row layout (more strips per block than the 64-column tiling)
+    bool vk_overlap = false;
+    std::vector<int> poff_ov;
+    int poff_edge_ov = 0, nwg_apply_ov = 0;
     std::vector<int> poff;          // partial-row offset of each owned block's K2 launch
     int poff_edge = 0, nwg_apply = 0, nwg_vec = 0;
     std::vector<int> poff2, rows2;  // same for the fused two-sweep launches, and their rows per workgroup
