@@ -573,15 +573,15 @@ def main():
             print(f"[bench] stream probe failed: {e}", file=sys.stderr)
             stream = None
         # north_star's "single 4096^2 elliptic sweep >= 60 % of the HBM roofline" in the same line: ONE sweep per launch (K2) on the same
-        # block, 48 launches event-timed outside the timed region (that pass is bandwidth-bound and runs below the power cap)
+        # block, 96 launches event-timed outside the timed region, behind 480 untimed ones (that pass is bandwidth-bound and runs below the power cap)
         single_ref = None
         if world == 1 and args.config == 2 and fused:
             try:
                 m1 = configs.single_block(n, n)
                 with smooth.Smoother(m1, solver.Option.hip(inner=solver.Inner.relax, single_sweep=True), stream=torch.cuda.current_stream().cuda_stream) as s1:
-                    s1.iterate(24)
+                    s1.iterate(480)   # its own settling: a fresh handle, and this pass draws less power than the one just timed
                     s1.profile(max(1, args.profile_every))
-                    s1.iterate(48)
+                    s1.iterate(96)
                     ms1, timed1, _ = s1.profile_read()
                 us1 = ms1 * 1e3 / max(1, timed1)
                 single_ref = {"kernel": "k_apply<RELAX,DELTA,field,laplace> (K2: one sweep per launch)", "avg_launch_us": us1,

@@ -140,6 +140,10 @@ enum {
                                 are formed inside the two operator applications (two kernels per iteration; rho from r_hat.s -
                                 omega r_hat.t, equal in exact arithmetic) and, on small meshes, the scalar steps travel with the
                                 kernels that consume them.  Same method, iterates equal to rounding */
+    TM_OPT_PRECOND_ILU0 = 8, /* tm_csr_solve ONLY (the slot that has the assembled matrix): ILU(0) -- the reference's second preconditioner
+                                (preconditioner.zig:1-4; BiCGStab.zig:178-277, 384-422) -- as right preconditioner of the device BiCGStab: factor
+                                and substitutions level by level on the device, bit-identical to the reference's recurrence.  The matrix-free
+                                entry points answer TM_E_UNSUPPORTED: they never assemble a matrix to factorise                        */
     TM_OPT_RTOL_INITIAL = 4  /* Krylov modes: `rtol` is relative to the INITIAL residual of each inner solve (inexact Picard: stop at
                                 ||D^-1(b-Ax)|| <= max(atol, rtol ||D^-1(b-A x0)||), rtol = 0 -> 1e-2) instead of ||D^-1 b||.  Every solve then
                                 does work in proportion to what is left -- same fixed point, several times fewer inner iterations on the way

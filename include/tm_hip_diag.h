@@ -28,6 +28,11 @@ int tm_stream_probe(uint64_t bytes, int32_t iters, double* copy_GBps, double* tr
  * reference's libm algorithm, Zig std.math = musl's, wall_control_function.zig:298-308).  Host arrays in and out. */
 int tm_white_math_probe(const double* x, const double* y, uint64_t n, double* out_acos, double* out_atan2);
 
+/* Diagnostic: ILU(0) of one CSR matrix on the device as tm_csr_solve's TM_OPT_PRECOND_ILU0 builds it -- the factor in A's own pattern into
+ * lu_out [nnz] and, when rhs / z_out are given, M^-1 rhs into z_out [n] (BiCGStab.zig:178-277, 384-422).  Host arrays. */
+int tm_csr_ilu0_probe(uint64_t n, const int32_t* Ap, const int32_t* Ai, const double* Ax, const double* rhs /* may be NULL */, double* lu_out,
+                      double* z_out /* may be NULL */);
+
 /* How the handle orders the two queues of a pipelined pass (interior pass on its stream, perimeter-row chain + halo exchange on a second,
  * high-priority stream of its own): counters in device memory with one-wave announce / wait kernels need the two streams on different
  * hardware queues, which HIP does not promise -- so the handle TESTS it once, when the second stream is created (one announce-and-wait

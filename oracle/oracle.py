@@ -427,6 +427,23 @@ def picard_direct(mesh, iterations, control=None, keep_iterates=False):
 
 
 # ------------------------------------------------------------------ stand-alone CSR solvers
+def csr_ilu0(n, Ap, Ai, Ax, rhs=None):
+    """ILU(0) of a CSR matrix in its own pattern (BiCGStab.zig:178-277) and, with rhs, M^-1 rhs (:384-422).  Returns (lu [nnz], out [n] or None)."""
+    Ap = np.ascontiguousarray(Ap, dtype=np.int32)
+    Ai = np.ascontiguousarray(Ai, dtype=np.int32)
+    Ax, Axp = _f64(Ax)
+    lu = np.empty(len(Ax))
+    out = None
+    rp = None
+    if rhs is not None:
+        rhs, rp = _f64(rhs)
+        out = np.empty(n)
+    L = lib()
+    L.orc_csr_ilu0.argtypes = [C.c_uint64, _ip, _ip, _dp, _dp, _dp, _dp]
+    _check(L.orc_csr_ilu0(C.c_uint64(n), Ap.ctypes.data_as(_ip), Ai.ctypes.data_as(_ip), Axp, rp, lu.ctypes.data_as(_dp), None if out is None else out.ctypes.data_as(_dp)))
+    return lu, out
+
+
 def csr_solve(kind, n, Ap, Ai, Ax, b, x0=None, precond=PRECOND_DIAGONAL, restart=30, max_iters=1000, rtol=1e-6, atol=1e-8):
     Ap = np.ascontiguousarray(Ap, dtype=np.int32)
     Ai = np.ascontiguousarray(Ai, dtype=np.int32)

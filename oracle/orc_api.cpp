@@ -204,6 +204,12 @@ int orc_csr_bicgstab(uint64_t n, const int32_t* Ap, const int32_t* Ai, const dou
         return r.converged ? ORC_OK : 1;
     });
 }
+int orc_csr_ilu0(uint64_t n, const int32_t* Ap, const int32_t* Ai, const double* Ax, const double* rhs, double* lu_out, double* out) {
+    return guarded([&]() {
+        ilu0_factor_apply(CsrView{n, Ap, Ai, Ax}, rhs, lu_out, out);
+        return ORC_OK;
+    });
+}
 int orc_csr_gmres(uint64_t n, const int32_t* Ap, const int32_t* Ai, const double* Ax, const double* b, double* x, int precond,
                   uint64_t restart, uint64_t max_iters, double rtol, double atol, uint64_t* iters) {
     return guarded([&]() {

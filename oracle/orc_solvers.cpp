@@ -127,6 +127,17 @@ struct Preconditioner {
 
 }  // namespace
 
+// ILU(0) alone (BiCGStab.zig:178-277 factorisation, :384-422 application): the factor in the CSR's own pattern and M^-1 rhs, for tests that
+// check a device implementation of the preconditioner bit for bit
+void ilu0_factor_apply(const CsrView& A, const Float* rhs, Float* lu_out, Float* out) {
+    Preconditioner M;
+    M.kind = ilu0;
+    M.update(A);
+    const Index nnz = static_cast<Index>(A.p[A.n]);
+    if (lu_out) std::copy(M.lu.begin(), M.lu.begin() + nnz, lu_out);
+    if (rhs && out) M.applyIlu0(A, rhs, out);
+}
+
 // ---------------------------------------------------------------- BiCGStab.zig:279-370
 SolveReport bicgstab(const CsrView& A, const Float* rhs, Float* x, Precond pc, Index max_iters, Float rtol, Float atol) {
     const Index n = A.n;

@@ -95,6 +95,7 @@ struct CsrView {
     const Float* v;
 };
 SolveReport bicgstab(const CsrView& A, const Float* rhs, Float* x, Precond pc, Index max_iters, Float rtol, Float atol);
+void ilu0_factor_apply(const CsrView& A, const Float* rhs, Float* lu_out, Float* out);   // BiCGStab.zig:178-277, 384-422
 SolveReport gmres(const CsrView& A, const Float* rhs, Float* x, Precond pc, Index restart, Index max_iters, Float rtol,
                   Float atol);
 SolveReport scaled_bicgstab(const CsrView& A, const Float* rhs, Float* x, Index max_iters, Float rtol, Float atol);

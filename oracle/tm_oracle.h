@@ -140,6 +140,9 @@ int orc_csr_bicgstab(uint64_t n, const int32_t* Ap, const int32_t* Ai, const dou
 int orc_csr_gmres(uint64_t n, const int32_t* Ap, const int32_t* Ai, const double* Ax, const double* b, double* x,
                   int precond, uint64_t restart, uint64_t max_iters, double rtol, double atol, uint64_t* iters);
 int orc_csr_direct(uint64_t n, const int32_t* Ap, const int32_t* Ai, const double* Ax, const double* b, double* x);
+/* ILU(0) alone: the factor in the CSR's own pattern (BiCGStab.zig:178-277) into lu_out [nnz] and M^-1 rhs (:384-422) into out [n];
+ * rhs / out may be NULL (factor only) */
+int orc_csr_ilu0(uint64_t n, const int32_t* Ap, const int32_t* Ai, const double* Ax, const double* rhs, double* lu_out, double* out);
 
 /* ---- timing helpers for bench.py's cpu_baseline leg (single thread) ---- */
 /* One reference-style inner BiCGStab(diagonal) iteration block on an ni x nj single block:

@@ -7,6 +7,7 @@ usage: worker.py <mode> <topology> <ni> <nj> <iterations> <out.json>
   mode      relax    -- Jacobi sweeps (pairs / triples schedule): every rank's blocks must equal the single-handle run bit for bit
             krylov   -- Picard + BiCGStab, hooked recurrence with ncclAllReduce: bit-identical to the torch.distributed (gloo) hooks at
                         world 2, and within 1e-10 rms of the single-handle run
+            gmres    -- the same with GMRES(30) as the inner solver (every Gram-Schmidt inner product is an all-reduce)
   topology  strip | strip_rev | junction   (strip: `world` x $TM_WORKER_BLOCKS_PER_RANK blocks stacked in i; junction: configs.two_by_two, one block per rank)"""
 import json
 import os
@@ -42,7 +43,8 @@ def main():
     nb = 4 if topology == "junction" else world * bpr
     owner = [b // bpr for b in range(nb)]
     owned = [b for b in range(nb) if owner[b] == rank]
-    opt = solver.Option.hip(inner=solver.Inner.relax) if mode == "relax" else solver.Option.hip(rtol=1e-13)
+    opt = (solver.Option.hip(inner=solver.Inner.relax) if mode == "relax" else
+           solver.Option.hip(inner=solver.Inner.gmres, rtol=1e-13, max_inner=20000) if mode == "gmres" else solver.Option.hip(rtol=1e-13))
     mesh = build(set(owned))
     h = tmd.RcclHooks(mesh, owner=owner, rank=rank, world=world, option=opt)
     st = h.iterate(its)
@@ -51,7 +53,7 @@ def main():
     result = {"rank": rank, "world": world, "outer_iterations": int(st["outer_iterations"]), "inner_iterations": int(st["inner_iterations"])}
 
     other = None
-    if mode == "krylov":   # the same job through the torch.distributed hooks (gloo: halo rows and scalars staged through the host)
+    if mode in ("krylov", "gmres"):   # the same job through the torch.distributed hooks (gloo: halo rows and scalars staged through the host)
         mesh_t = build(set(owned))
         ht = tmd.TorchHooks(mesh_t, owner=owner, rank=rank, world=world, option=opt)
         ht.iterate(its)
@@ -73,7 +75,7 @@ def main():
         want = np.stack([whole.blocks[b].points.data for b in range(nb)])
         result["bit_identical_to_single_handle"] = bool(np.array_equal(got, want))
         result["rms_vs_single_handle"] = float(np.sqrt(np.mean((got - want) ** 2)))
-        result["bit_identical_to_torch_hooks"] = None if mode != "krylov" else bool(all(flags))
+        result["bit_identical_to_torch_hooks"] = None if mode == "relax" else bool(all(flags))
         with open(out_path, "w") as f:
             json.dump(result, f)
     dist.barrier()

@@ -18,7 +18,7 @@ def _declared_in(header):
     return sorted(names)
 
 
-DIAGNOSTIC = ["tm_smoother_profile", "tm_smoother_profile_read", "tm_smoother_queue_ordering", "tm_stream_probe", "tm_white_math_probe"]
+DIAGNOSTIC = ["tm_csr_ilu0_probe", "tm_smoother_profile", "tm_smoother_profile_read", "tm_smoother_queue_ordering", "tm_stream_probe", "tm_white_math_probe"]
 
 
 def _declared_functions():

@@ -118,10 +118,12 @@ def test_relax_sweeps_over_reversed_interfaces_and_the_junction_mesh(topology, w
 
 
 @pytest.mark.gpu
-def test_krylov_path_over_tm_rccl_allreduce(tmp_path):
-    # Picard + BiCGStab on two ranks: halo exchange per operator application + ncclAllReduce of the reduction scalars, both issued by tm_rccl.cpp.
-    # Two summands commute, so the run is bit-identical to the torch.distributed hooks; a single handle sums in another order: <= 1e-10 rms.
+@pytest.mark.parametrize("mode", ["krylov", "gmres"])
+def test_krylov_path_over_tm_rccl_allreduce(mode, tmp_path):
+    # Picard + BiCGStab (and GMRES(30): an all-reduce per Gram-Schmidt inner product) on two ranks: halo exchange per operator application +
+    # ncclAllReduce of the reduction scalars, both issued by tm_rccl.cpp.  Two summands commute, so the run is bit-identical to the
+    # torch.distributed hooks; a single handle sums in another order: <= 1e-10 rms.
     assert _build()
-    res = _worker(2, ["krylov", "strip", 40, 56, 2], _env(), tmp_path)
+    res = _worker(2, [mode, "strip", 40, 56, 2], _env(), tmp_path)
     assert res["bit_identical_to_torch_hooks"] is True, res
     assert res["rms_vs_single_handle"] <= 1e-10, res

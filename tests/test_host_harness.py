@@ -25,6 +25,8 @@ def test_harness_built_and_fails_loudly_without_arguments():
     (["strip", "3", "17", "24", "3", "bicgstab"], lambda: configs.strip(3, 17, 24, tfi=oracle_tfi)),
     (["single", "33", "41", "3", "bicgstab"], lambda: configs.single_block(33, 41, tfi=oracle_tfi)),
     (["strip", "3", "33", "40", "3", "mg"], lambda: configs.strip(3, 33, 40, tfi=oracle_tfi)),   # multigrid-preconditioned inner solve
+    (["strip", "3", "17", "24", "3", "gmres"], lambda: configs.strip(3, 17, 24, tfi=oracle_tfi)),  # GMRES(30) on the device, default tolerance
+    (["single", "33", "41", "3", "auto"], lambda: configs.single_block(33, 41, tfi=oracle_tfi)),    # the size-aware choice (here: bicgstab)
 ])
 def test_harness_matches_oracle(tmp_path, args, builder):
     dump = str(tmp_path / "dump.bin")

@@ -24,3 +24,15 @@ for eager in (False, True, False, True):
     dt = time.perf_counter() - t0
     print(f"{name} n={len(bx)} {'launch per step' if eager else 'lazy steps     '}: rc {rc}, {st['inner_iterations']} inner iterations, {dt * 1e3:.1f} ms wall, "
           f"{st['seconds'] * 1e6 / max(1, st['inner_iterations']):.1f} us per iteration (whole call)", flush=True)
+# ILU(0) in the slot (TM_OPT_PRECOND_ILU0): the reference's preconditioner of its example inputs, level-scheduled on the device
+from turbomesh_amd.smoothing import solver
+for rep in range(2):
+    t0 = time.perf_counter()
+    x, y, rc, st = csr_solve(Ap, Ai, Ax, bx, by, x0=x0, y0=y0, Ay=Ay, rtol=1e-10, max_inner=5000, preconditioner=solver.Preconditioner.ilu0)
+    dt = time.perf_counter() - t0
+    print(f"{name} n={len(bx)} ILU(0), level-scheduled: rc {rc}, {st['inner_iterations']} inner iterations, {dt * 1e3:.1f} ms wall, "
+          f"{st['seconds'] * 1e6 / max(1, st['inner_iterations']):.0f} us per iteration (whole call, analysis + factorisation included)", flush=True)
+# the CPU oracle's faithful BiCGStab + ILU(0) on the same system, x component, for the iteration count (its stop test is the reference's unscaled one)
+t0 = time.perf_counter()
+xo, its, ok = oracle.csr_solve("bicgstab", len(bx), Ap, Ai, Ax, bx, x0=x0, precond=oracle.PRECOND_ILU0, max_iters=5000, rtol=1e-12, atol=0.0)
+print(f"{name} CPU oracle BiCGStab + ILU(0), x component, rtol 1e-12 (unscaled): {its} iterations, {(time.perf_counter() - t0) * 1e3:.1f} ms, converged {ok}")

@@ -1,7 +1,7 @@
 #!/bin/bash
 # The probes behind the numbers DESIGN.md / README.md quote, in one run on the MI355X box (through gpurun, from the repo root):
 #   tools/measure_round.sh r02   ->  gpurun_out/<tag>_measurements.txt   (copy into profiles/)
-tag=${1:-r03}
+tag=${1:-r04}
 out=gpurun_out/${tag}_measurements.txt
 mkdir -p gpurun_out
 {
@@ -30,5 +30,12 @@ mkdir -p gpurun_out
   echo "## perturbed 4096^2 block to a scaled residual <= 1e-8 (tools/solve_probe.py)"; python3 tools/solve_probe.py 4096 1e-6 1e-6 1e-10 2>/dev/null
   echo "## the same with one operator application per pass in the multigrid cycle (TM_MG_PAIR=0)"; TM_MG_PAIR=0 python3 tools/solve_probe.py 4096 1e-6 1e-6 1e-10 2>/dev/null
   echo "## host-buffer seam, PCIe inclusive (tools/oneshot_probe.py)"; python3 tools/oneshot_probe.py 2>/dev/null | tail -4
+  echo "## cross-queue ordering by mechanism + the co-residency self-test (tools/ubench/queue_order.hip), then the same with GPU_MAX_HW_QUEUES=1"
+  [ -x tools/ubench/queue_order_bin ] || /opt/rocm/bin/hipcc --offload-arch=gfx950 -O2 -o tools/ubench/queue_order_bin tools/ubench/queue_order.hip 2>/dev/null
+  if [ -x tools/ubench/queue_order_bin ]; then timeout -k 10 120 ./tools/ubench/queue_order_bin 2000 | grep -v "^done"; GPU_MAX_HW_QUEUES=1 timeout -k 10 120 ./tools/ubench/queue_order_bin 300 | grep -E "GPU_MAX|self-test"; fi
+  echo "## BiCGStab iteration by size: 64-column tiles with halo loads / overlapping 62-column strips (tools/dev/vk_overlap_sizes.py)"
+  python3 tools/dev/vk_overlap_sizes.py 1024 1448 2048 2896 4096 2>/dev/null
+  echo "## GMRES(30) on the device against BiCGStab: T106 as written, 10 Picard iterations (tools/t106_probe.py T106 gmres)"
+  python3 tools/t106_probe.py T106 gmres 2>/dev/null | tail -1
 } > "$out" 2>&1
 cat "$out"

@@ -150,6 +150,8 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     if (o->inner != TM_INNER_BICGSTAB && o->inner != TM_INNER_RELAX && o->inner != TM_INNER_MG_BICGSTAB && o->inner != TM_INNER_AUTO && o->inner != TM_INNER_GMRES)
         throw TmError(TM_E_ARG, "unknown inner strategy");
     opt = *o;
+    if (opt.flags & TM_OPT_PRECOND_ILU0)
+        throw TmError(TM_E_UNSUPPORTED, "ILU(0) needs the assembled matrix: it is served by tm_csr_solve (seam 2); the matrix-free path preconditions with the diagonal or the multigrid cycle");
     if (opt.inner == TM_INNER_AUTO) {   // size-aware choice, from the global topology alone (include/tm_hip.h)
         uint64_t largest = 0;
         if (mesh && mesh->blocks)

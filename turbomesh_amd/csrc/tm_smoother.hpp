@@ -150,8 +150,8 @@ struct Smoother {
     void upload(const tm_mesh_desc* mesh);
     void download(const tm_mesh_desc* mesh);
     void iterate(uint64_t iterations, tm_stats* stats);
-    bool iterate_until(uint64_t max_iterations, double tol, tm_stats* stats);
-    bool iterate_until_update(uint64_t max_iterations, double tol, tm_stats* stats);   // true = the scaled residual reached tol
+    bool iterate_until(uint64_t max_iterations, double tol, tm_stats* stats);          // true = the scaled residual reached tol
+    bool iterate_until_update(uint64_t max_iterations, double tol, tm_stats* stats);   // true = the update of the last outer iteration was <= tol
     double stop_tol = 0.0;          // > 0: a Picard iteration whose start residual is already <= stop_tol returns without solving
     void apply_host(const double* in_xy, double* out_xy, int scaled);
     void rhs_host(double* rhs_xy);

@@ -202,9 +202,12 @@ int main(int argc, char** argv) {
         smoothing::solver::Option opt;
         if (a < argc && std::strcmp(argv[a], "relax") == 0) opt.inner = TM_INNER_RELAX;
         if (a < argc && std::strcmp(argv[a], "mg") == 0) opt.inner = TM_INNER_MG_BICGSTAB;
-        if (a < argc && (std::strcmp(argv[a], "relax") == 0 || std::strcmp(argv[a], "bicgstab") == 0 || std::strcmp(argv[a], "mg") == 0)) ++a;
-        opt.rtol = 1e-13;
-        opt.max_inner = 5000;
+        if (a < argc && std::strcmp(argv[a], "gmres") == 0) opt.inner = TM_INNER_GMRES;   // GMRES(30) on the device (GMRES.zig:300-423)
+        if (a < argc && std::strcmp(argv[a], "auto") == 0) opt.inner = TM_INNER_AUTO;
+        const bool tight_default = a < argc && (std::strcmp(argv[a], "gmres") == 0 || std::strcmp(argv[a], "auto") == 0);
+        if (a < argc && (std::strcmp(argv[a], "relax") == 0 || std::strcmp(argv[a], "bicgstab") == 0 || std::strcmp(argv[a], "mg") == 0 || tight_default)) ++a;
+        opt.rtol = tight_default ? 0.0 : 1e-13;   // gmres / auto: the library's own default tolerance
+        opt.max_inner = tight_default ? 0 : 5000;
         // "until <tol>" after the solver name: iterate to a residual through the device-resident handle instead of a fixed count
         double until = 0.0;
         std::string plot3d;

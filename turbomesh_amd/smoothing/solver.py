@@ -74,8 +74,11 @@ class Option:
         return Option.hip(inner=inner), note
 
     def c_struct(self):
+        # preconditioner: the payload of the reference's gmres / bicgstab options; with the hip tag it selects ILU(0) in the linear-solver slot
+        # (Solver / tm_csr_solve, TM_OPT_PRECOND_ILU0) -- the matrix-free smoother refuses it (no assembled matrix to factorise)
+        ilu = 8 if (self.tag == Tag.hip and self.preconditioner == Preconditioner.ilu0) else 0
         return _capi.tm_solver_opt(int(self.tag), int(self.inner), self.rtol, self.atol, self.max_inner, self.check_every,
-                                   (1 if self.single_sweep else 0) | (2 if self.eager_scalars else 0) | (4 if self.rtol_initial else 0), self.omega)
+                                   (1 if self.single_sweep else 0) | (2 if self.eager_scalars else 0) | (4 if self.rtol_initial else 0) | ilu, self.omega)
 
 
 class Solver:
