@@ -278,6 +278,12 @@ int tm_rccl_unique_id(const char* librccl_path, void* id_out /* TM_RCCL_ID_BYTES
 int tm_rccl_comm_create(const char* librccl_path, const void* id, int32_t rank, int32_t nranks, tm_rccl_comm** out);
 void tm_rccl_comm_destroy(tm_rccl_comm* comm);
 int tm_rccl_hooks(tm_rccl_comm* comm, const tm_mesh_desc* mesh, const int32_t* owner /* [nblocks] */, tm_comm_hooks* hooks);
+/* The same when the options of the handle the hooks are for are known (pass the very structures given to tm_smoother_create): a handle that
+ * never runs sweep triples -- the Krylov modes, the White control function, TM_OPT_SINGLE_SWEEP -- then exchanges the depth-2 halo only
+ * (tm_rccl_hooks sizes its tables by the topology alone: depth 3 on blocks of 2^19 nodes and more, whatever the handle does with it).
+ * A handle created with the library's own hooks follows the depth their tables were built for. */
+int tm_rccl_hooks_for(tm_rccl_comm* comm, const tm_mesh_desc* mesh, const int32_t* owner, const tm_solver_opt* opt, const tm_control_fn* cf /* NULL = laplace */,
+                      tm_comm_hooks* hooks);
 
 /* The table tm_rccl_hooks builds for a rank, host-only (no communicator, no GPU): per neighbouring rank the offset and count
  * (rows of 16 B) handed to ncclSend / ncclRecv in one group per exchange.  Pairwise symmetry -- send_cnt of a towards b ==

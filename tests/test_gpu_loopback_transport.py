@@ -127,3 +127,6 @@ def test_krylov_path_over_tm_rccl_allreduce(mode, tmp_path):
     res = _worker(2, [mode, "strip", 40, 56, 2], _env(), tmp_path)
     assert res["bit_identical_to_torch_hooks"] is True, res
     assert res["rms_vs_single_handle"] <= 1e-10, res
+    if mode == "krylov":   # blocks that count as large: the transport's tables are built for the handle's options (tm_rccl_hooks_for: depth 2, like the torch hooks' plan)
+        res = _worker(2, [mode, "strip", 40, 56, 2], _env(TM_TRIPLES_MIN_NODES="1"), tmp_path)
+        assert res["bit_identical_to_torch_hooks"] is True and res["rms_vs_single_handle"] <= 1e-10, res

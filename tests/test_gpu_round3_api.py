@@ -170,3 +170,22 @@ def test_inner_auto_is_decided_by_the_largest_block():
     import numpy as np
 
     assert float(np.sqrt(np.mean((a.blocks[0].points.data - b.blocks[0].points.data) ** 2))) <= 1e-10
+
+
+def test_a_handle_that_never_runs_triples_exchanges_the_depth_2_halo_only(monkeypatch):
+    # the depth-3 ghost set (one exchange per sweep TRIPLE) used to be exchanged by every handle on large blocks, Krylov modes
+    # included.  Now the depth follows the handle's options -- identical on every rank -- and the library's own transport builds its tables
+    # for them (tm_rccl_hooks_for).  Threshold lowered so that these small blocks count as large.
+    from turbomesh_amd import distributed as tmd
+
+    monkeypatch.setenv("TM_TRIPLES_MIN_NODES", "1")
+    rows = {}
+    for name, opt in (("relax", solver.Option.hip(inner=solver.Inner.relax)), ("single_sweep", solver.Option.hip(inner=solver.Inner.relax, single_sweep=True)),
+                      ("bicgstab", solver.Option.hip()), ("gmres", solver.Option.hip(inner=solver.Inner.gmres))):
+        h = tmd.TorchHooks(tmd.strip_for_rank(3, 1, 40, 50), owner=[0, 1, 2], rank=1, world=3, option=opt)   # rank 1 of 3: neighbours on both sides; never iterated
+        rows[name] = (int(sum(h.plan["recv_count"])), int(sum(h.plan["send_count"])))
+        h.smoother.close()
+    assert rows["bicgstab"] == rows["gmres"] == rows["single_sweep"]
+    assert rows["relax"][0] > rows["bicgstab"][0] and rows["relax"][1] > rows["bicgstab"][1], rows
+    # a strip: the solved side of an interface sends 3 rows for triples and 2 for pairs, the slaved side 4 and 3
+    assert rows["relax"] == (7 * 50, 7 * 50) and rows["bicgstab"] == (5 * 50, 5 * 50), rows

@@ -116,7 +116,7 @@ EXPORTS = [
     "tm_smoother_exchange_plan", "tm_smoother_apply", "tm_smoother_rhs", "tm_smoother_row_kinds", "tm_smoother_dof",
     "tm_smoother_control_function", "tm_smoother_profile", "tm_smoother_profile_read", "tm_plan_build", "tm_plan_free", "tm_plan_local", "tm_plan_local_free", "tm_dev_tfi_block", "tm_dev_relax_sweep",
     "tm_dev_relax_partials_needed", "tm_export_soa", "tm_smoother_export_soa", "tm_rccl_unique_id", "tm_rccl_comm_create", "tm_rccl_comm_destroy", "tm_rccl_hooks",
-    "tm_rccl_peer_table_build", "tm_rccl_peer_table_free", "tm_white_math_probe", "tm_stream_probe", "tm_smoother_queue_ordering", "tm_smoother_inner", "tm_csr_ilu0_probe",
+    "tm_rccl_peer_table_build", "tm_rccl_peer_table_free", "tm_white_math_probe", "tm_stream_probe", "tm_smoother_queue_ordering", "tm_smoother_inner", "tm_csr_ilu0_probe", "tm_rccl_hooks_for",
 ]
 
 _lib = None
@@ -198,6 +198,7 @@ def lib():
         L.tm_rccl_comm_destroy.argtypes = [C.c_void_p]
         L.tm_rccl_comm_destroy.restype = None
         L.tm_rccl_hooks.argtypes = [C.c_void_p, C.POINTER(tm_mesh_desc), C.POINTER(C.c_int32), C.POINTER(tm_comm_hooks)]
+        L.tm_rccl_hooks_for.argtypes = [C.c_void_p, C.POINTER(tm_mesh_desc), C.POINTER(C.c_int32), C.POINTER(tm_solver_opt), C.POINTER(tm_control_fn), C.POINTER(tm_comm_hooks)]
         L.tm_plan_local.argtypes = [C.POINTER(tm_mesh_desc), C.POINTER(C.c_int32), C.c_int32, C.c_int32, C.POINTER(tm_plan_local_info)]
         L.tm_plan_local_free.argtypes = [C.POINTER(tm_plan_local_info)]
         L.tm_plan_local_free.restype = None

@@ -497,7 +497,7 @@ bool triple_halo_for(const Topology& t, int nranks) {
 }
 
 LocalPlan build_local_plan(const Topology& t, const std::vector<PlanRow>& all_rows, const std::vector<int32_t>& owner, int rank,
-                           int nranks) {
+                           int nranks, bool allow_triples) {
     LocalPlan lp;
     lp.rank = rank;
     lp.nranks = nranks;
@@ -569,9 +569,11 @@ LocalPlan build_local_plan(const Topology& t, const std::vector<PlanRow>& all_ro
     }
     need.swap(need2);
     // depth 3 (sweep TRIPLES on large coupled blocks, Smoother::relax_triples_coupled): the rows of the depth-2 set are evaluated one
-    // level further down (ghost_rows2: their definitions), and the remote rows THOSE read travel too.  Decided from the topology alone,
-    // so every rank -- and tm_rccl_hooks, which builds its tables from this function as well -- agrees on the exchange lists.
-    lp.triple_halo = triple_halo_for(t, nranks);
+    // level further down (ghost_rows2: their definitions), and the remote rows THOSE read travel too.  Decided from the topology -- and
+    // from whether the caller's handles will run triples at all (allow_triples: a pure function of the solver options, identical on every
+    // rank; a Krylov / White / single-sweep handle exchanges the depth-2 set only) -- so every rank and the transport's tables, which are
+    // built from this function as well (tm_rccl_hooks / tm_rccl_hooks_for), agree on the exchange lists.
+    lp.triple_halo = allow_triples && triple_halo_for(t, nranks);
     if (lp.triple_halo) {
         std::vector<std::vector<std::pair<int32_t, int64_t>>> need3 = need;
         for (int r = 0; r < nranks; ++r) {

@@ -112,6 +112,6 @@ struct LocalPlan {
 };
 bool triple_halo_for(const Topology& t, int nranks);
 LocalPlan build_local_plan(const Topology& t, const std::vector<PlanRow>& all_rows, const std::vector<int32_t>& owner, int rank,
-                           int nranks);
+                           int nranks, bool allow_triples = true);
 
 }  // namespace tmh

@@ -186,7 +186,14 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
             nranks = h->nranks;
             owner.assign(h->owner, h->owner + topo.nblocks());
         }
-        lp = build_local_plan(topo, all_rows, owner, rank, nranks);
+        // depth of the halo: what this handle's schedule needs -- unless the hooks are the library's own transport, whose send / receive
+        // tables were built when the hooks were made and rule (tm_rccl_hooks: by topology; tm_rccl_hooks_for: by the options)
+        bool allow_triples = triples_wanted(opt, cf);
+        if (has_hooks) {
+            const int t = rccl_hooks_allow_triples(h);
+            if (t >= 0) allow_triples = t != 0;
+        }
+        lp = build_local_plan(topo, all_rows, owner, rank, nranks, allow_triples);
     } catch (const PlanError& e) {
         throw TmError(e.code, e.what());
     }

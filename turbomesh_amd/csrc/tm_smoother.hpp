@@ -1,6 +1,7 @@
 // Device-resident smoother handle (internal).  One handle = one rank's share of a mesh.
 #pragma once
 #include "../../include/tm_hip.h"
+#include <cstdlib>
 #include "tm_kernels.h"
 #include "tm_multigrid.hpp"
 #include "tm_plan.hpp"
@@ -236,6 +237,16 @@ struct Smoother {
 // 6.5e-11 at 2049^2 and 6e-10 at 4096^2 with rtol 1e-14.  Hence rtol = 7.5e-9 / nodes, between 1e-16 and 1e-14: every size lands
 // at <= 3e-11, for 0-40 % more inner iterations on the large meshes (the recurrence residual keeps falling; no stagnation seen down
 // to 1e-16).  The iteration cap grows with the mesh too: BiCGStab with the diagonal alone needs ~3-5 sqrt(nodes) iterations.
+// Will a handle with these options ever run sweep TRIPLES across ranks (the only schedule that needs the depth-3 halo)?  A pure function of
+// the options (and of TM_TRIPLES_COUPLED in the environment), identical on every rank of a job.
+inline bool triples_wanted(const tm_solver_opt& o, const tm_control_fn& c) {
+    if (o.inner != TM_INNER_RELAX || c.kind != TM_CF_LAPLACE || (o.flags & TM_OPT_SINGLE_SWEEP)) return false;
+    if (const char* e = std::getenv("TM_TRIPLES_COUPLED")) return std::atoi(e) != 0;
+    return true;
+}
+// the library's own transport: non-negative = the depth its tables were built for (0: depth 2, 1: depth 3 where the topology has it); -1 = foreign hooks
+int rccl_hooks_allow_triples(const tm_comm_hooks* h);
+
 // TM_INNER_AUTO: the multigrid-preconditioned solve from this many nodes in the largest block on (include/tm_hip.h)
 constexpr uint64_t AUTO_MG_MIN_BLOCK_NODES = 100000;
 

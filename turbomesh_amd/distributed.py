@@ -300,7 +300,12 @@ class RcclHooks:
         self._owner = (C.c_int32 * len(owner))(*owner)
         self._md = _capi.MeshDesc(mesh)
         self._hooks = _capi.tm_comm_hooks()
-        _capi.check(L.tm_rccl_hooks(self._comm, self._md.ref(), self._owner, C.byref(self._hooks)))
+        # tables for THIS handle's options: a handle that never runs sweep triples exchanges the depth-2 halo only
+        from .smoothing import wall_control_function as _wcf
+
+        self._opt_c = (option or _solver.Option.hip()).c_struct()
+        self._cf_c = (control or _wcf.Algorithm.laplace()).c_struct()
+        _capi.check(L.tm_rccl_hooks_for(self._comm, self._md.ref(), self._owner, C.byref(self._opt_c), C.byref(self._cf_c), C.byref(self._hooks)))
         self.smoother = smooth.Smoother(mesh, option, control, hooks=self._hooks, stream=torch.cuda.current_stream(device).cuda_stream)
 
     def iterate(self, iterations):
