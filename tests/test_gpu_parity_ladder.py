@@ -142,6 +142,30 @@ def test_4096_two_routes_to_the_same_picard_iterates():
         log_parity(f"block4096_{inner.name}_true_scaled_residual_over_fp64_storage_floor", both / floor)
         print(f"[4096] {inner.name}: true scaled residual vs the oracle-assembled system {both:.2e} = {both / floor:.1f} x the fp64 storage floor {floor:.2e}")
         assert both <= bound * floor and both <= 1e-12, (inner.name, both, floor)
+    # ... and the OPERATOR itself at this size, row by row, against the reference-order arithmetic: A(X^0) w through the matrix-free kernels
+    # (tm_smoother_apply) vs the oracle-assembled CSR times w (scipy: the sum of the nine products in CSR order, i.e. BiCGStab.zig:424-435) --
+    # perimeter rows bit for bit, interior rows within 16 eps sum_k |c_k w_k| (the factored row evaluation; tests/test_gpu_operator.py holds
+    # the same bound on the small topologies, here on all 16.7 M rows)
+    import scipy.sparse as sp
+
+    A = sp.csr_matrix((v, ci, p), shape=(n * n, n * n))
+    w = np.random.default_rng(11).standard_normal((n * n, 2))
+    blk = configs.block_from_array(x0.copy())
+    from turbomesh_amd.discrete import Mesh
+
+    m0 = Mesh()
+    m0.addBlock("b", blk)
+    with smooth.Smoother(m0, solver.Option.hip()) as sm:
+        got = sm.apply(w, scaled=False)
+        kinds = sm.row_kinds()
+    ref = np.stack([A @ w[:, 0], A @ w[:, 1]], axis=1)
+    perim = kinds >= 0
+    assert np.array_equal(got[perim], ref[perim])
+    absA = abs(A)
+    bnd = 16 * np.finfo(float).eps * np.stack([absA @ np.abs(w[:, 0]), absA @ np.abs(w[:, 1])], axis=1)
+    worst = float((np.abs(got - ref) / (bnd + 1e-300)).max())
+    log_parity("block4096_operator_vs_reference_order_csr_worst_over_16eps_bound", worst)
+    assert worst <= 1.0, worst
 
 
 def test_1025_three_routes_one_of_them_through_the_oracle_assembled_csr():
