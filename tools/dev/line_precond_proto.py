@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""CPU prototype (numpy / scipy on the oracle-assembled system of an example input, iteration 0): BiCGStab iterations to rtol 1e-10 on the
+row-equilibrated operator with the diagonal alone, with line relaxation along j, along i, alternating (j then i, one residual in
+between), and with ILU(0) -- before anyone writes batched tridiagonal solves for the GPU.  Result (round 4): T106 442 / 319 / 348 / 144 /
+788, LS89 658 / 579 / 718 / 456 / 1043 -- the alternating sweep costs two line solves and an operator application per use and so does not
+pay, the single directions gain a quarter at best.  usage: line_precond_proto.py [T106|LS89]"""
+import sys, time, numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
+from oracle import oracle
+from tests.conftest import OracleMesh, oracle_tfi
+import bench
+name = sys.argv[1] if len(sys.argv)>1 else 'T106'
+from tests.test_o4h import load
+_, mesh = load(name, oracle_tfi)
+om = OracleMesh(mesh)
+s = oracle.System(om); s.fill(0); s.fill_x_specific()
+A = s.csr().tocsr(); b = s.rhs_x.copy(); n = A.shape[0]
+x0 = om.flat()[:,0].copy()
+d = A.diagonal(); Dinv = sp.diags(1.0/d)
+B = (Dinv @ A).tocsr(); bs = b/d
+# block layout
+shapes=[bl.shape[:2] for bl in om.blocks]; offs=np.cumsum([0]+[a*c for a,c in shapes])
+def line_factor(direction):
+    # tridiagonal part of B along lines within each block (direction 'j': consecutive ids; 'i': stride nj)
+    rows=[];cols=[];vals=[]
+    Bc=B.tocoo()
+    keep=np.zeros(Bc.nnz,bool)
+    blk=np.searchsorted(offs,Bc.row,side='right')-1
+    blkc=np.searchsorted(offs,Bc.col,side='right')-1
+    same=blk==blkc
+    nj=np.array([sh[1] for sh in shapes])[blk]
+    lr=Bc.row-offs[blk]; lc=Bc.col-offs[blk]
+    ir,jr=lr//nj,lr%nj; ic,jc=lc//nj,lc%nj
+    if direction=='j': keep=same&(ir==ic)&(np.abs(jr-jc)<=1)
+    else: keep=same&(jr==jc)&(np.abs(ir-ic)<=1)
+    T=sp.csr_matrix((Bc.data[keep],(Bc.row[keep],Bc.col[keep])),shape=(n,n))
+    return spla.splu(T.tocsc())
+def bicgstab(apply_prec, rtol=1e-10, maxit=5000):
+    x=x0.copy(); r=bs-B@x; rh=r.copy(); rho=alpha=om_=1.0; v=np.zeros(n); p=np.zeros(n)
+    tol=rtol*np.linalg.norm(bs)
+    for it in range(1,maxit+1):
+        rho_new=rh@r; beta=(rho_new/rho)*(alpha/om_); p=r+beta*(p-om_*v)
+        ph=apply_prec(p); v=B@ph; alpha=rho_new/(rh@v); s_=r-alpha*v
+        sh=apply_prec(s_); t=B@sh; om_=(t@s_)/(t@t); x+=alpha*ph+om_*sh; r=s_-om_*t; rho=rho_new
+        if np.linalg.norm(r)<=tol: return it
+    return maxit
+print(name,'n',n)
+print('diag      ', bicgstab(lambda v:v))
+Lj=line_factor('j'); Li=line_factor('i')
+print('line j    ', bicgstab(lambda v:Lj.solve(v)))
+print('line i    ', bicgstab(lambda v:Li.solve(v)))
+def adi(v):
+    y=Lj.solve(v); r2=v-B@y; return y+Li.solve(r2)
+print('adi j->i  ', bicgstab(adi), '(2 line solves + 1 matvec per application)')
+ilu=spla.spilu(B.tocsc(),drop_tol=0,fill_factor=1)
+print('spilu(0)  ', bicgstab(lambda v:ilu.solve(v)))
