@@ -162,6 +162,24 @@ struct EdgeRowsDev {
     const double* rhs = nullptr;        // [nrows*2] static right-hand side, run order
 };
 constexpr int EDGE_BLOCK = 128;
+// The three level passes of a coupled sweep triple in ONE launch (Smoother::relax_triples_coupled): the rows of level 3 are cut into
+// strips along their grid lines; a workgroup owns one strip and evaluates -- redundantly, with the very run descriptors of the three
+// level tables -- every level-1 and level-2 row its strip depends on (the closure is computed on the host), level by level with a barrier
+// in between.  What a workgroup reads at level l it wrote itself at level l - 1 (or nobody writes it at all), so no workgroup waits for
+// another; neighbouring strips store the same bits where their closures overlap.  One kernel boundary instead of three on the
+// latency-critical chain.  A task = up to 64 consecutive points of one run, taken by one wave (the descriptor stays wave-uniform).
+struct LevelTask {
+    int32_t run, k0, count;
+};
+struct FusedLevelsDev {
+    int nstrips = 0;
+    const LevelTask* tasks = nullptr;   // all strips, level by level
+    const int32_t* off = nullptr;       // [nstrips * 4]: tasks of level l of strip s are off[4 s + l] .. off[4 s + l + 1]
+};
+constexpr int LEVELS_BLOCK = 512;
+hipError_t launch_edge_levels3(const FusedLevelsDev& F, const EdgeRowsDev& e1, const EdgeRowsDev& e2, const EdgeRowsDev& e3, const double2* x, double2* m,
+                               double2* m2, double2* out, const double2* pq, double omega, int dot, double* partials /* [nstrips * MAX_PARTIALS] */,
+                               hipStream_t stream);
 // out/in/xk/pq/aux are the rank-local vectors (owned rows then ghost rows)
 // signal != nullptr: the kernel's first thread bumps *signal as it starts -- "everything in front of this launch in its queue is
 // complete and visible device-wide" (what launch_queue_signal would announce from a launch of its own)
@@ -205,6 +223,8 @@ hipError_t launch_queue_signal(uint32_t* counter, hipStream_t stream);
 hipError_t launch_queue_wait(const uint32_t* counter, uint32_t target, uint32_t* error, hipStream_t stream, long long limit_ticks = QUEUE_WAIT_TICKS);
 hipError_t launch_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error, hipStream_t stream,
                                     long long limit_ticks = QUEUE_WAIT_TICKS);
+
+hipError_t launch_delay_us(double us, hipStream_t stream);   // measurement support: a one-wave kernel that lasts `us` microseconds
 
 // ---- reductions: sum partial rows [nwg][MAX_PARTIALS] in fixed order into red[MAX_PARTIALS]
 hipError_t launch_finalize(const double* partials, int nwg, double* red, hipStream_t stream);

@@ -1861,6 +1861,47 @@ __global__ __launch_bounds__(EDGE_BLOCK) void k_edge_rows(EdgeRowsDev e, const d
     if (DOT != DOT_NONE) block_partials<EDGE_BLOCK, dot_columns(DOT)>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
 
+// The three level passes of a coupled sweep triple in one launch (FusedLevelsDev, tm_kernels.h): strip `blockIdx.x`, levels 1..3 with a
+// barrier in between; a wave takes whole tasks, so the run descriptor is wave-uniform as in k_edge_rows.  Same edge_row_eval, same bits.
+template <int DOT>
+__global__ __launch_bounds__(LEVELS_BLOCK) void k_edge_levels3(FusedLevelsDev F, EdgeRowsDev e1, EdgeRowsDev e2, EdgeRowsDev e3, const double2* x, double2* m,
+                                                               double2* m2, double2* out, const double2* __restrict__ pq, double omega, double* partials) {
+    const int s = blockIdx.x;
+    const int wave = static_cast<int>(threadIdx.x) >> 6, lane = static_cast<int>(threadIdx.x) & 63;
+    constexpr int NW = LEVELS_BLOCK / 64;
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    auto level = [&](const EdgeRowsDev& e, int l, const double2* in, double2* dst, auto dot_tag) {
+        constexpr int D = decltype(dot_tag)::value;
+        const int t0 = F.off[4 * s + l], t1 = F.off[4 * s + l + 1];
+        for (int t = t0 + wave; t < t1; t += NW) {
+            const int run = __builtin_amdgcn_readfirstlane(F.tasks[t].run);
+            const int k0 = __builtin_amdgcn_readfirstlane(F.tasks[t].k0), cnt = __builtin_amdgcn_readfirstlane(F.tasks[t].count);
+            const EdgeRun& R = e.runs[run];
+            if (lane < cnt) {
+                double2 o;
+                int row;
+                edge_row_eval<MODE_RELAX, D>(R, e.rhs, k0 + lane, [&](int, int id) { return in[id]; }, [&](int, int id) { return in[id]; },
+                                             [&](int id) { return in[id]; }, pq, nullptr, omega, acc, o, row);
+                dst[row] = o;
+            }
+        }
+    };
+    level(e1, 0, x, m, std::integral_constant<int, DOT_NONE>{});
+    __syncthreads();   // workgroup-scope release / acquire: level 2 reads what this workgroup stored at level 1
+    level(e2, 1, m, m2, std::integral_constant<int, DOT_NONE>{});
+    __syncthreads();
+    level(e3, 2, m2, out, std::integral_constant<int, DOT>{});
+    if (DOT != DOT_NONE) block_partials<LEVELS_BLOCK, dot_columns(DOT)>(acc, partials + static_cast<size_t>(s) * MAX_PARTIALS);
+}
+hipError_t launch_edge_levels3(const FusedLevelsDev& F, const EdgeRowsDev& e1, const EdgeRowsDev& e2, const EdgeRowsDev& e3, const double2* x, double2* m,
+                               double2* m2, double2* out, const double2* pq, double omega, int dot, double* partials, hipStream_t st) {
+    if (F.nstrips == 0) return hipSuccess;
+    if (dot == DOT_DELTA) hipLaunchKernelGGL(k_edge_levels3<DOT_DELTA>, dim3(F.nstrips), dim3(LEVELS_BLOCK), 0, st, F, e1, e2, e3, x, m, m2, out, pq, omega, partials);
+    else if (dot == DOT_NONE) hipLaunchKernelGGL(k_edge_levels3<DOT_NONE>, dim3(F.nstrips), dim3(LEVELS_BLOCK), 0, st, F, e1, e2, e3, x, m, m2, out, pq, omega, partials);
+    else return hipErrorInvalidValue;
+    return hipGetLastError();
+}
+
 // Interior rows of up to APPLY_BATCH_MAX blocks AND the perimeter rows of the rank in ONE launch (single-process handles: the
 // perimeter rows read nothing the interior pass writes, and nothing has to arrive from another rank in between).  Small meshes --
 // the reference's own inputs: 8 blocks, 25-38 k nodes -- are bound by dependent kernel launches (~5 us each), and the two passes
@@ -2291,6 +2332,19 @@ __global__ __launch_bounds__(64) void k_queue_signal_wait(uint32_t* counter, con
 }
 hipError_t launch_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error, hipStream_t st, long long limit_ticks) {
     hipLaunchKernelGGL(k_queue_signal_wait, dim3(1), dim3(64), 0, st, counter, other, target, error, limit_ticks);
+    return hipGetLastError();
+}
+// measurement support (libtm_hip_dbg.so's null transport): one wave that keeps its queue busy for `us` microseconds of the constant
+// 100 MHz clock -- the device time of a halo exchange that moves nothing, so that a rank's schedule can be timed with the exchange
+// ON its chain without peers
+__global__ __launch_bounds__(64) void k_delay(long long ticks) {
+    if (threadIdx.x != 0) return;
+    const long long t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) __builtin_amdgcn_s_sleep(8);
+}
+hipError_t launch_delay_us(double us, hipStream_t st) {
+    if (!(us > 0.0)) return hipSuccess;
+    hipLaunchKernelGGL(k_delay, dim3(1), dim3(64), 0, st, static_cast<long long>(us * 100.0));
     return hipGetLastError();
 }
 hipError_t launch_queue_signal(uint32_t* counter, hipStream_t st) {

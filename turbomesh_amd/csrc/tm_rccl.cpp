@@ -8,6 +8,7 @@
 // librccl is loaded at run time (dlopen) so that the process uses ONE RCCL -- the copy the host framework already loaded,
 // when there is one (the caller passes its path) -- and so that libtm_hip.so has no link-time dependency on it.
 #include "tm_api_util.hpp"
+#include "tm_kernels.h"
 #include "tm_plan.hpp"
 #include "tm_smoother.hpp"
 
@@ -249,7 +250,11 @@ int tm_debug_null_hooks(int32_t rank, int32_t nranks, const int32_t* owner, tm_c
     hooks->rank = rank;
     hooks->nranks = nranks;
     hooks->owner = owner;
-    hooks->exchange = [](void*, const double*, double*, void*) { return 0; };
+    // TM_NULL_EXCHANGE_US=t: every exchange occupies the stream it is issued on for t microseconds (a one-wave kernel): the device time
+    // of a real transfer ON the chain, without peers
+    static double delay_us = 0.0;
+    if (const char* e = std::getenv("TM_NULL_EXCHANGE_US")) delay_us = std::atof(e);
+    hooks->exchange = [](void*, const double*, double*, void* stream) { return launch_delay_us(delay_us, static_cast<hipStream_t>(stream)) == hipSuccess ? 0 : 1; };
     hooks->exchange_wait = [](void*, void*) { return 0; };
     hooks->allreduce_sum = [](void*, double*, int32_t, void*) { return 0; };
     return TM_OK;

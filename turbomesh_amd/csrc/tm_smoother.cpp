@@ -15,6 +15,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
+#include <unordered_map>
 
 namespace tmh {
 
@@ -297,12 +299,21 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     // Per-row table -> runs (tm_kernels.h EdgeRun).  Rows are grouped by everything that must be equal along a run (static fields
     // and the grid line of their block they lie on), sorted by row id within a group and cut wherever an index stops advancing by
     // the stride of the stretch.  order[p] = position in `sel` of the row whose right-hand side sits at position p of e.rhs.
-    auto build_table = [&](const std::vector<const PlanRow*>& sel, EdgeRowsDev& e, double*& rhs_dev, std::vector<int32_t>& order) {
+    // (keep != nullptr: the host copy of the runs and, per run, where it lies -- block, direction, which half of the block, position of
+    //  its first point along the line and the position step -- for the strip plan of the fused level kernel)
+    struct RunWhere {
+        int64_t side_key;            // (block, runs along rows or columns, lower or upper half of the block)
+        int32_t pos0, pos_stride;
+    };
+    auto build_table = [&](const std::vector<const PlanRow*>& sel, EdgeRowsDev& e, double*& rhs_dev, std::vector<int32_t>& order,
+                           std::vector<EdgeRun>* keep = nullptr, std::vector<RunWhere>* keep_where = nullptr) {
         const size_t n = sel.size();
         struct HostRow {
             int32_t row, col[9], met[4];
             uint8_t flags;
             int64_t line;   // (block, grid line) the node lies on: rows of different lines never share a run
+            int64_t side_key;
+            int32_t pos;
         };
         std::vector<HostRow> hr(n);
         auto loc = [&](int64_t gid) {
@@ -330,6 +341,9 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
                 if (h.row < lp.n_owned) h.flags |= 16;
             }
             h.line = (b << 34) | (static_cast<int64_t>(on_row ? 0 : 1) << 33) | (on_row ? bi : bj);
+            const int64_t across = on_row ? bi : bj, across_n = on_row ? topo.ni[b] : topo.nj[b];
+            h.side_key = (b << 2) | (static_cast<int64_t>(on_row ? 0 : 1) << 1) | (2 * across >= across_n ? 1 : 0);
+            h.pos = static_cast<int32_t>(on_row ? bj : bi);
         }
         auto same_static = [&](size_t x, size_t y) {
             const PlanRow &p = *sel[x], &q = *sel[y];
@@ -399,8 +413,10 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
             }
             for (size_t j = p; j < e_; ++j) order.push_back(static_cast<int32_t>(idx[j]));
             runs.push_back(R);
+            if (keep_where) keep_where->push_back(RunWhere{hr[k0].side_key, hr[k0].pos, e_ - p > 1 ? hr[idx[p + 1]].pos - hr[k0].pos : 0});
             p = e_;
         }
+        if (keep) *keep = runs;
         std::vector<int32_t> wg_run, wg_k0;
         for (size_t r = 0; r < runs.size(); ++r)
             for (int32_t k0 = 0; k0 < runs[r].count; k0 += EDGE_BLOCK) {
@@ -458,6 +474,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
             // level l (1..3) evaluates the moving perimeter rows and, as KIND_INTERIOR rows (K2's own arithmetic on the gathered 3 x 3
             // neighbourhood), the interior nodes within 5 - l of a side whose perimeter rows move (Chebyshev distance: the 9-point
             // stencil's dependency cone); what level l reads at level l - 1 lies within 6 - l of such a side or on the perimeter
+            std::vector<RunWhere> where_L3;
             for (int lev = 0; lev < 3; ++lev) {
                 const int64_t depth = 4 - lev;
                 zone_rows[lev].clear();
@@ -495,7 +512,76 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
                 // definitions, hence their owners' bits); level 3 reads them
                 if (lev == 0) for (const PlanRow& g : lp.ghost_rows2) sl.push_back(&g);
                 if (lev == 1) for (const PlanRow& g : lp.ghost_rows) sl.push_back(&g);
-                build_table(sl, edge_L[lev], d_rhs_L[lev], order_L[lev]);
+                build_table(sl, edge_L[lev], d_rhs_L[lev], order_L[lev], &runs_L[lev], lev == 2 ? &where_L3 : nullptr);
+            }
+            // ---- strip plan of the fused level kernel (k_edge_levels3): level-3 rows by strips of LEVEL_STRIP positions along their lines,
+            // per side of a block; per strip the level-2 rows its level-3 rows read, and the level-1 rows THOSE read (hulls per run)
+            levels_fused = true;
+            if (const char* e = std::getenv("TM_LEVELS_FUSED")) levels_fused = std::atoi(e) != 0;
+            if (levels_fused) {
+                int LEVEL_STRIP = 60;   // positions per strip: 60 + 2 x 2 halo positions make whole 64-point wave tasks at level 1
+                if (const char* e = std::getenv("TM_LEVEL_STRIP")) LEVEL_STRIP = std::max(4, std::atoi(e));
+                std::unordered_map<int32_t, std::pair<int32_t, int32_t>> made[2];   // local row id -> (run, k) in the level-1 / level-2 table
+                for (int lev = 0; lev < 2; ++lev)
+                    for (size_t r = 0; r < runs_L[lev].size(); ++r)
+                        for (int32_t k = 0; k < runs_L[lev][r].count; ++k)
+                            made[lev][runs_L[lev][r].row0 + k * runs_L[lev][r].row_stride] = {static_cast<int32_t>(r), k};
+                auto reads = [&](const EdgeRun& R, int32_t k, auto&& f) {   // every local id row k of run R reads at the previous level
+                    for (int q = 0; q < R.ncols; ++q) f(R.col0[q] + k * R.col_stride[q]);
+                    if (R.kind == KIND_SMOOTHED)
+                        for (int q = 0; q < 4; ++q) f(R.met0[q] + k * R.met_stride[q]);
+                    f(R.row0 + k * R.row_stride);
+                };
+                using Hull = std::map<int32_t, std::pair<int32_t, int32_t>>;   // run -> [kmin, kmax]
+                auto widen = [](Hull& h, int32_t run, int32_t k) {
+                    auto it = h.find(run);
+                    if (it == h.end()) h[run] = {k, k};
+                    else {
+                        it->second.first = std::min(it->second.first, k);
+                        it->second.second = std::max(it->second.second, k);
+                    }
+                };
+                std::map<std::pair<int64_t, int32_t>, Hull> strips;   // (side, strip number) -> level-3 rows
+                for (size_t r = 0; r < runs_L[2].size(); ++r)
+                    for (int32_t k = 0; k < runs_L[2][r].count; ++k)
+                        widen(strips[{where_L3[r].side_key, (where_L3[r].pos0 + k * where_L3[r].pos_stride) / LEVEL_STRIP}], static_cast<int32_t>(r), k);
+                std::vector<LevelTask> tasks;
+                std::vector<int32_t> off;
+                auto emit = [&](const Hull& h) {
+                    for (const auto& kv : h)
+                        for (int32_t k = kv.second.first; k <= kv.second.second; k += 64)
+                            tasks.push_back(LevelTask{kv.first, k, std::min<int32_t>(64, kv.second.second - k + 1)});
+                };
+                for (const auto& st : strips) {
+                    // a strip's level-3 rows need not be one range per run (two strips of one run are separate map entries: they are);
+                    // level 2 = hull of what they read and level 2 makes, level 1 = hull of what THAT hull reads and level 1 makes
+                    Hull h2, h1;
+                    for (const auto& kv : st.second)
+                        for (int32_t k = kv.second.first; k <= kv.second.second; ++k)
+                            reads(runs_L[2][kv.first], k, [&](int32_t id) {
+                                auto it = made[1].find(id);
+                                if (it != made[1].end()) widen(h2, it->second.first, it->second.second);
+                            });
+                    for (const auto& kv : h2)
+                        for (int32_t k = kv.second.first; k <= kv.second.second; ++k)
+                            reads(runs_L[1][kv.first], k, [&](int32_t id) {
+                                auto it = made[0].find(id);
+                                if (it != made[0].end()) widen(h1, it->second.first, it->second.second);
+                            });
+                    off.push_back(static_cast<int32_t>(tasks.size()));
+                    emit(h1);
+                    off.push_back(static_cast<int32_t>(tasks.size()));
+                    emit(h2);
+                    off.push_back(static_cast<int32_t>(tasks.size()));
+                    emit(st.second);
+                    off.push_back(static_cast<int32_t>(tasks.size()));
+                }
+                fused_levels.nstrips = static_cast<int>(strips.size());
+                fused_levels.tasks = static_cast<const LevelTask*>(up(tasks.data(), tasks.size() * sizeof(LevelTask)));
+                fused_levels.off = static_cast<const int32_t*>(up(off.data(), off.size() * 4));
+                if (std::getenv("TM_DEBUG_RUNS"))
+                    std::fprintf(stderr, "[tm] fused level kernel: %d strips, %zu wave tasks (level tables: %d / %d / %d rows)\n", fused_levels.nstrips, tasks.size(),
+                                 edge_L[0].nrows, edge_L[1].nrows, edge_L[2].nrows);
             }
         }
     }
@@ -581,7 +667,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         nwg_apply3 = off3;
     }
     nwg_vec = vec_nwg(n_owned);
-    const int nwg3_all = fuse_triples ? nwg_apply3 : (triples_coupled ? nwg_apply3 + edge_L[2].nwg : 0);
+    const int nwg3_all = fuse_triples ? nwg_apply3 : (triples_coupled ? nwg_apply3 + std::max(edge_L[2].nwg, fused_levels.nstrips) : 0);
     // Overlapping strips for the two kernels of the two-kernel BiCGStab iteration (single process, no preconditioner -- where fuse2 holds,
     // below): no halo registers -> 234 instead of 276 VGPRs for VK_R, two workgroups per CU without spills.  Where it pays was MEASURED, same
     // box, alternating runs (tools/dev/vk_overlap_sizes.py, us per iteration halo loads / overlapping strips): 1024^2 74.4 / 80.0,
@@ -1470,9 +1556,14 @@ void Smoother::relax_triples_coupled(uint64_t ntriples, bool want_partials_last)
         }
         exchange(X, side);                 // several ranks: X^k of the depth-3 ghost set, once per triple (a no-op otherwise)
         exchange_finish(side);
-        HIPCHK(launch_edge_rows(edge_L[0], X, X, PQ, nullptr, M, opt.omega, MODE_RELAX, DOT_NONE, partials, side));
-        HIPCHK(launch_edge_rows(edge_L[1], M, M, PQ, nullptr, M2, opt.omega, MODE_RELAX, DOT_NONE, partials, side));
-        HIPCHK(launch_edge_rows(edge_L[2], M2, M2, PQ, nullptr, U, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(nwg_apply3) * MAX_PARTIALS, side));
+        if (levels_fused) {   // the three level passes in one launch: strips with their own closure of level-1 and level-2 rows (k_edge_levels3)
+            HIPCHK(launch_edge_levels3(fused_levels, edge_L[0], edge_L[1], edge_L[2], X, M, M2, U, PQ, opt.omega, dot,
+                                       partials + static_cast<size_t>(nwg_apply3) * MAX_PARTIALS, side));
+        } else {
+            HIPCHK(launch_edge_rows(edge_L[0], X, X, PQ, nullptr, M, opt.omega, MODE_RELAX, DOT_NONE, partials, side));
+            HIPCHK(launch_edge_rows(edge_L[1], M, M, PQ, nullptr, M2, opt.omega, MODE_RELAX, DOT_NONE, partials, side));
+            HIPCHK(launch_edge_rows(edge_L[2], M2, M2, PQ, nullptr, U, opt.omega, MODE_RELAX, dot, partials + static_cast<size_t>(nwg_apply3) * MAX_PARTIALS, side));
+        }
         if (q + 1 < ntriples && !use_flags) HIPCHK(hipEventRecord(ev_to_main, side));
         std::swap(X, U);
     }
@@ -1621,7 +1712,7 @@ void Smoother::relax_sweeps(uint64_t n, tm_stats& st) {
             last_nwg = nwg_apply3;
         } else {
             relax_triples_coupled(ntriples, n % 3 == 0);
-            last_nwg = nwg_apply3 + edge_L[2].nwg;
+            last_nwg = nwg_apply3 + (levels_fused ? fused_levels.nstrips : edge_L[2].nwg);
         }
         k = 3 * ntriples;
         st.operator_sweeps += k;

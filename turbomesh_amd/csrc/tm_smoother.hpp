@@ -123,6 +123,9 @@ struct Smoother {
     // perimeter rows move; three perimeter-row passes evaluate the perimeter and that zone level by level (rows within 4 / 3 / 2 nodes)
     bool triples_coupled = false;
     EdgeRowsDev edge_L[3];
+    std::vector<EdgeRun> runs_L[3];          // host copies of the three level tables' runs (strip plan of the fused level kernel)
+    bool levels_fused = false;               // the three level passes of a coupled triple in one launch (k_edge_levels3; TM_LEVELS_FUSED=0: three launches)
+    FusedLevelsDev fused_levels;
     double* d_rhs_L[3] = {nullptr, nullptr, nullptr};
     std::vector<int32_t> order_L[3];
     std::vector<PlanRow> zone_rows[3];   // KIND_INTERIOR rows of the zones (level 1: distance <= 4, level 2: <= 3, level 3: <= 2)
