@@ -280,7 +280,7 @@ void tm_rccl_comm_destroy(tm_rccl_comm* comm);
 int tm_rccl_hooks(tm_rccl_comm* comm, const tm_mesh_desc* mesh, const int32_t* owner /* [nblocks] */, tm_comm_hooks* hooks);
 /* The same when the options of the handle the hooks are for are known (pass the very structures given to tm_smoother_create): a handle that
  * never runs sweep triples -- the Krylov modes, the White control function, TM_OPT_SINGLE_SWEEP -- then exchanges the depth-2 halo only
- * (tm_rccl_hooks sizes its tables by the topology alone: depth 3 on blocks of 2^19 nodes and more, whatever the handle does with it).
+ * (tm_rccl_hooks sizes its tables by the topology alone: depth 3 wherever every block has at least 16 x 16 nodes, whatever the handle does with it).
  * A handle created with the library's own hooks follows the depth their tables were built for. */
 int tm_rccl_hooks_for(tm_rccl_comm* comm, const tm_mesh_desc* mesh, const int32_t* owner, const tm_solver_opt* opt, const tm_control_fn* cf /* NULL = laplace */,
                       tm_comm_hooks* hooks);

@@ -36,6 +36,16 @@ def pytest_collection_modifyitems(config, items):
             item.add_marker(skip)
 
 
+@pytest.fixture(autouse=True)
+def _round3_triples_threshold(monkeypatch):
+    """The multi-rank tests were written around round 3's threshold -- blocks below 2^19 nodes take sweep PAIRS across ranks, larger ones
+    triples -- and between them cover both schedules; since round 4 the library's default is triples for every block of at least 16 x 16
+    nodes (tm_plan.cpp triple_halo_for).  Keep the old threshold inside the test process so that the pair schedule stays covered; tests of
+    the triples on small blocks set TM_TRIPLES_MIN_NODES=1 themselves, subprocess tests choose explicitly (-1 = pairs, 1 = triples)."""
+    if "TM_TRIPLES_MIN_NODES" not in os.environ:
+        monkeypatch.setenv("TM_TRIPLES_MIN_NODES", str(1 << 19))
+
+
 @pytest.fixture(scope="session", autouse=True)
 def _built():
     """Make sure the oracle and the HIP library exist (built by __graft_entry__.build())."""

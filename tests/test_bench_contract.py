@@ -90,7 +90,7 @@ def test_bench_gpus4_config4_rehearsal_on_one_gpu_is_bit_identical_to_one_handle
     env.pop("TM_PAIR_SYNC", None)
     if pair_sync == "events":
         env["TM_PAIR_SYNC"] = "events"
-    env.pop("TM_TRIPLES_MIN_NODES", None)
+    env["TM_TRIPLES_MIN_NODES"] = "-1"   # the PAIR schedule (since round 4 the default is triples at every size)
     if pair_sync == "triples":   # sweep triples across ranks (depth-3 halo, one exchange per triple): the threshold lowered to these 96^2 blocks
         env["TM_TRIPLES_MIN_NODES"] = "1"
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--config", "4", "--size", "96", "--steps", "21", "--warmup", "4",

@@ -76,7 +76,7 @@ def test_bench_gpus4_config4_through_tm_rccl_is_bit_identical_to_one_handle(sche
     # pairs: depth-2 halo, one exchange per sweep pair, counters; triples: depth-3 halo, one exchange per triple, announce-and-wait kernels;
     # events: the same with hipEvent ordering.  4 ranks + this process <= 6 processes on the card.
     assert _build()
-    extra = {"events": {"TM_PAIR_SYNC": "events", "TM_TRIPLES_MIN_NODES": "1"}, "triples": {"TM_TRIPLES_MIN_NODES": "1"}, "pairs": {}}[schedule]
+    extra = {"events": {"TM_PAIR_SYNC": "events", "TM_TRIPLES_MIN_NODES": "1"}, "triples": {"TM_TRIPLES_MIN_NODES": "1"}, "pairs": {"TM_TRIPLES_MIN_NODES": "-1"}}[schedule]
     j = _bench(["--gpus", "4", "--config", "4", "--size", "96", "--steps", "21", "--warmup", "4"], _env(**extra))
     assert j["n_gpus"] == 4 and j["scaling"] == "strong" and j["config"]["nodes_per_gpu"] == 2 * 96 * 96
     assert j["config"]["verified_against_single_handle"] is True
@@ -112,7 +112,7 @@ def test_relax_sweeps_over_reversed_interfaces_and_the_junction_mesh(topology, w
     # reversed ranges (ascending on one side, descending on the other) and the 2 x 2 junction mesh (every rank has two neighbours and the
     # centre node's row reads three remote blocks): pairs first, then triples with the threshold lowered
     assert _build()
-    for extra in ({}, {"TM_TRIPLES_MIN_NODES": "1"}):
+    for extra in ({"TM_TRIPLES_MIN_NODES": "-1"}, {"TM_TRIPLES_MIN_NODES": "1"}):
         res = _worker(world, ["relax", topology, ni, nj, its], _env(**extra), tmp_path)
         assert res["bit_identical_to_single_handle"] is True, res
 

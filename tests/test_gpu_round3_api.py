@@ -189,3 +189,18 @@ def test_a_handle_that_never_runs_triples_exchanges_the_depth_2_halo_only(monkey
     assert rows["relax"][0] > rows["bicgstab"][0] and rows["relax"][1] > rows["bicgstab"][1], rows
     # a strip: the solved side of an interface sends 3 rows for triples and 2 for pairs, the slaved side 4 and 3
     assert rows["relax"] == (7 * 50, 7 * 50) and rows["bicgstab"] == (5 * 50, 5 * 50), rows
+
+
+def test_default_schedule_across_ranks_is_triples_at_every_size(monkeypatch):
+    # round 4: with the three level passes of a triple in one launch, triples beat pairs down to 256^2 blocks (tools/dev/triples_threshold.sh),
+    # so the library's own default -- no TM_TRIPLES_MIN_NODES in the environment -- is the depth-3 halo for every block of at least 16 x 16 nodes
+    from turbomesh_amd import distributed as tmd
+
+    monkeypatch.delenv("TM_TRIPLES_MIN_NODES", raising=False)
+    relax = solver.Option.hip(inner=solver.Inner.relax)
+    h = tmd.TorchHooks(tmd.strip_for_rank(3, 1, 40, 50), owner=[0, 1, 2], rank=1, world=3, option=relax)
+    assert int(sum(h.plan["recv_count"])) == 7 * 50
+    h.smoother.close()
+    h = tmd.TorchHooks(tmd.strip_for_rank(3, 1, 12, 50), owner=[0, 1, 2], rank=1, world=3, option=relax)   # blocks below 16 rows: pairs
+    assert int(sum(h.plan["recv_count"])) == 5 * 50
+    h.smoother.close()

@@ -22,8 +22,7 @@ for case in range(cases):
     env = dict(os.environ, TM_RCCL_LIB=LB, HSA_ENABLE_IPC_MODE_LEGACY="0", TM_WORKER_BLOCKS_PER_RANK=str(bpr), TM_LOOPBACK_WAIT_S="60")
     for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "TM_PAIR_SYNC", "TM_TRIPLES_MIN_NODES"):
         env.pop(k, None)
-    if triples:
-        env["TM_TRIPLES_MIN_NODES"] = "1"
+    env["TM_TRIPLES_MIN_NODES"] = "1" if triples else "-1"
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]

@@ -481,14 +481,15 @@ int64_t LocalPlan::to_local(int64_t gid) const {
     return g == ghost_index.end() ? -1 : n_owned + g->second;
 }
 
-// Sweep triples across ranks pay when three sweeps of a rank's block outlast the chain of three perimeter-row passes (and the exchange
-// costs a third less per sweep than with pairs): measured with a transport that moves nothing, rank 1 of 3 (tools/split_path_cost.py,
-// settled clocks), us per sweep triples / pairs: 4096^2 41.3 / 55.4, 2048^2 13.1 / 16.7, 1448^2 10.5 / 12.7, 1024^2 8.0 / 10.1,
-// 724^2 8.3 / 8.4, 512^2 10.0 / 9.1.  A pure function of the topology (TM_TRIPLES_MIN_NODES overrides the threshold: tests, A/B
-// runs; negative = never), identical on every rank.
+// Sweep triples across ranks: one exchange of a depth-3 halo per three sweeps instead of one of a depth-2 halo per two.  Round 3 found
+// them slower than pairs below ~2^19 nodes per block (three level launches per triple on the chain: 512^2 10.0 against 9.1 us per sweep);
+// since the three level passes run as ONE launch (k_edge_levels3) triples win at every size -- rank 1 of 3, null transport, us per sweep
+// triples / pairs (tools/dev/triples_threshold.sh): 256^2 4.2 / 7.6, 512^2 4.5 / 8.0, 1024^2 5.4 / 10.2; with 10 us of exchange on the
+// chain 7.5 / 12.8, 7.4 / 13.2, 8.1 / 14.6 -- so every block of at least 16 x 16 nodes takes them.  A pure function of the topology
+// (TM_TRIPLES_MIN_NODES overrides the threshold: tests, A/B runs; negative = never), identical on every rank.
 bool triple_halo_for(const Topology& t, int nranks) {
     if (nranks < 2) return false;
-    int64_t min_nodes = int64_t{1} << 19;
+    int64_t min_nodes = 0;
     if (const char* e = std::getenv("TM_TRIPLES_MIN_NODES")) min_nodes = std::atoll(e);
     if (min_nodes < 0) return false;
     for (int64_t b = 0; b < t.nblocks(); ++b)
