@@ -44,6 +44,8 @@ def _round3_triples_threshold(monkeypatch):
     the triples on small blocks set TM_TRIPLES_MIN_NODES=1 themselves, subprocess tests choose explicitly (-1 = pairs, 1 = triples)."""
     if "TM_TRIPLES_MIN_NODES" not in os.environ:
         monkeypatch.setenv("TM_TRIPLES_MIN_NODES", str(1 << 19))
+    if "TM_TRIPLES_SINGLE_MIN_NODES" not in os.environ:   # the same for coupled blocks in ONE process: 2^20 owned nodes in round 3, none since
+        monkeypatch.setenv("TM_TRIPLES_SINGLE_MIN_NODES", str(1 << 20))
 
 
 @pytest.fixture(scope="session", autouse=True)

@@ -95,3 +95,34 @@ def test_config5_independent_slices_equal_separate_runs():
             sm.iterate(2)
             sm.download()
         assert float(np.sqrt(np.mean((a.blocks[k].points.data - one.blocks[0].points.data) ** 2))) <= 2e-10
+
+
+SMALL_COUPLED = {
+    "strip3_reversed_20x24": lambda: configs.strip(3, 20, 24, reverse_odd=True),
+    "strip2_17x70": lambda: configs.strip(2, 17, 70),
+    "junction_20x22": lambda: configs.two_by_two(20, 22),
+    "channel_periodic_sliding_21x25": lambda: configs.periodic_channel(21, 25),
+    "channel_periodic_fixed_24x19": lambda: configs.periodic_channel(24, 19, sliding=False),
+    "junction_33x16": lambda: configs.two_by_two(33, 16),
+}
+
+
+@pytest.mark.parametrize("name", list(SMALL_COUPLED))
+@pytest.mark.parametrize("sweeps", [3, 10])
+def test_default_schedule_on_small_coupled_meshes_is_the_triple_path_and_bit_identical(name, sweeps, monkeypatch):
+    # Round 4: with the three level passes in one launch (k_edge_levels3) coupled sweep triples win at every size, so the library's own
+    # default -- no thresholds in the environment -- takes them on any coupled mesh whose blocks have at least 16 x 16 nodes.  Here on the
+    # irregular topologies at small sizes: junction rows, periodic and sliding rows, reversed interfaces all pass through the strips'
+    # host-computed closures; the result must equal single sweeps bit for bit, with the fused level kernel and with three launches.
+    monkeypatch.delenv("TM_TRIPLES_SINGLE_MIN_NODES", raising=False)
+    monkeypatch.delenv("TM_TRIPLES_MIN_NODES", raising=False)
+    ref = SMALL_COUPLED[name]()
+    smooth.mesh(ref, sweeps, solver.Option.hip(inner=solver.Inner.relax, single_sweep=True))
+    for fused in ("1", "0"):
+        monkeypatch.setenv("TM_LEVELS_FUSED", fused)
+        got = SMALL_COUPLED[name]()
+        with smooth.Smoother(got, solver.Option.hip(inner=solver.Inner.relax)) as sm:
+            sm.iterate(sweeps)
+            assert sm.queue_ordering()[0] >= 0, "the two-queue triple schedule did not run"
+            sm.download()
+        assert np.array_equal(mesh_flat(got), mesh_flat(ref)), (name, sweeps, fused)

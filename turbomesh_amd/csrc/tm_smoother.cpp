@@ -267,7 +267,12 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         // ... or several ranks whose blocks are all large enough for the exchange of a depth-3 halo once per triple (LocalPlan::triple_halo,
         // decided from the topology alone: every rank with a neighbour takes the same schedule)
         const bool peers = has_hooks && (!lp.ghost_gid.empty() || !lp.send_ids.empty());
-        triples_coupled = fuse_pairs && any_nf && (peers ? lp.triple_halo : lp.n_owned >= (1 << 20));
+        // a single process with coupled blocks: triples (two queues, the level passes in one launch) at every size -- round 3 had them from 2^20
+        // owned nodes on; with the fused level kernel (tools/dev/triples_single_threshold.sh, us per sweep triples / pairs): 8 x 128^2 6.8 / 9.1,
+        // 8 x 256^2 6.1 / 10.2, 2 x 724^2 5.8 / 10.2, 8 x 512^2 10.8 / 13.2
+        int64_t single_min = 0;
+        if (const char* e = std::getenv("TM_TRIPLES_SINGLE_MIN_NODES")) single_min = std::atoll(e);
+        triples_coupled = fuse_pairs && any_nf && (peers ? lp.triple_halo : lp.n_owned >= single_min);
         for (int64_t b : lp.owned_blocks) triples_coupled = triples_coupled && topo.ni[b] >= 16 && topo.nj[b] >= 16 && relax3_supported(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]));
         if (const char* e = std::getenv("TM_TRIPLES_COUPLED")) triples_coupled = triples_coupled && std::atoi(e) != 0;
         if (triples_coupled) M2 = vec();
