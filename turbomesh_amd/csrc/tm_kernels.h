@@ -176,7 +176,7 @@ struct FusedLevelsDev {
     const LevelTask* tasks = nullptr;   // all strips, level by level
     const int32_t* off = nullptr;       // [nstrips * 4]: tasks of level l of strip s are off[4 s + l] .. off[4 s + l + 1]
 };
-constexpr int LEVELS_BLOCK = 512;
+constexpr int LEVELS_BLOCK = 512;   // (1024: no faster -- 2048^2 rank 11.9 against 10.8-11.8 us per sweep -- and twice the LDS)
 hipError_t launch_edge_levels3(const FusedLevelsDev& F, const EdgeRowsDev& e1, const EdgeRowsDev& e2, const EdgeRowsDev& e3, const double2* x, double2* m,
                                double2* m2, double2* out, const double2* pq, double omega, int dot, double* partials /* [nstrips * MAX_PARTIALS] */,
                                hipStream_t stream);
