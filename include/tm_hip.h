@@ -205,6 +205,8 @@ int tm_smooth_mesh(const tm_mesh_desc* mesh, uint64_t iterations, const tm_solve
  * differ in the two entries of every sliding row (system.fillXSpecific / fillYSpecific, smooth.zig:1115-1165): pass the
  * values after fillXSpecific as Ax_x and a copy taken after fillYSpecific as Ax_y (NULL = same values for both; exact
  * whenever the mesh has no inlet / outlet condition).  Both components are solved together on the device by BiCGStab
+ * -- or, with opt->inner == TM_INNER_GMRES, by the reference's restarted GMRES(30) (GMRES.zig:300-423), left-preconditioned; with
+ * TM_OPT_PRECOND_ILU0 in opt->flags either of them takes ILU(0) instead of the diagonal: the four combinations of solver.zig:18-27 --
  * on D^-1 A with the stop test of tm_solver_opt (rtol, atol, max_inner, check_every; opt may be NULL = defaults; rtol 0 -> 1e-14 here at
  * every size: the size-aware default belongs to the matrix-free path's own operator).  A recurrence residual that fails to halve over
  * max(4000, 4 sqrt(n)) iterations ends the solve as not converged.

@@ -120,3 +120,30 @@ def test_the_matrix_free_path_refuses_ilu0():
     with pytest.raises(_capi.TmError) as e:
         smooth.mesh(mesh, 1, solver.Option.hip(preconditioner=solver.Preconditioner.ilu0))
     assert e.value.code == _capi.TM_E_UNSUPPORTED and "seam 2" in str(e.value)
+
+
+@pytest.mark.parametrize("name", ["strip3_reversed", "channel_periodic_sliding", "two_by_two_junction"])
+@pytest.mark.parametrize("inner,precond", [(solver.Inner.gmres, solver.Preconditioner.diagonal), (solver.Inner.gmres, solver.Preconditioner.ilu0),
+                                           (solver.Inner.bicgstab, solver.Preconditioner.diagonal), (solver.Inner.bicgstab, solver.Preconditioner.ilu0)])
+def test_the_four_solver_preconditioner_combinations_of_the_reference_in_the_slot(name, inner, precond):
+    # solver.zig:18-27: gmres / bicgstab, each with preconditioner diagonal / ilu0 -- all four on the device in the linear-solver slot, on the
+    # caller's assembled system, both components; every one lands on the exact solve's solution (<= 1e-10 rms)
+    import scipy.sparse as sp
+    import scipy.sparse.linalg as spla
+
+    om, s = _system(name)
+    s.fill_x_specific()
+    vx = s.lhs_values.copy()
+    s.fill_y_specific()
+    vy = s.lhs_values.copy()
+    p, ci = s.lhs_p.copy(), s.lhs_i.copy()
+    bx, by = s.rhs_x.copy(), s.rhs_y.copy()
+    n = len(p) - 1
+    ref_x = spla.splu(sp.csr_matrix((vx, ci, p), shape=(n, n)).tocsc()).solve(bx)
+    ref_y = spla.splu(sp.csr_matrix((vy, ci, p), shape=(n, n)).tocsc()).solve(by)
+    x0 = om.flat()
+    two = not np.array_equal(vx, vy)
+    x, y, rc, st = csr_solve(p, ci, vx, bx, by, x0[:, 0], x0[:, 1], Ay=vy if two else None, rtol=1e-13, max_inner=30000, inner=inner, preconditioner=precond)
+    assert rc == 0, (inner.name, precond.name, st)
+    rms = float(np.sqrt(np.mean(np.concatenate([x - ref_x, y - ref_y]) ** 2)))
+    assert rms <= 1e-10, (inner.name, precond.name, rms, st["inner_iterations"])

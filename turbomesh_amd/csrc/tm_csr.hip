@@ -104,6 +104,18 @@ __global__ __launch_bounds__(256) void k_csr_bnorm(int n, const double2* __restr
     block_partials<256>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
 }
 
+// partials of ||v||^2 per component
+__global__ __launch_bounds__(256) void k_csr_norm2(int n, const double2* __restrict__ v, double* partials) {
+    const int row = blockIdx.x * 256 + threadIdx.x;
+    double acc[MAX_PARTIALS] = {0.0, 0.0, 0.0, 0.0};
+    if (row < n) {
+        const double2 w = v[row];
+        acc[0] = w.x * w.x;
+        acc[1] = w.y * w.y;
+    }
+    block_partials<256>(acc, partials + static_cast<size_t>(blockIdx.x) * MAX_PARTIALS);
+}
+
 __global__ __launch_bounds__(256) void k_interleave(int n, const double* __restrict__ a, const double* __restrict__ b, double2* __restrict__ out) {
     const int i = blockIdx.x * 256 + threadIdx.x;
     if (i < n) out[i] = make_double2(a[i], b[i]);
@@ -314,9 +326,14 @@ struct IluState {
         run<ILU_FACTOR>(L, d_ordL.as<int32_t>(), d_ptrL.as<int32_t>(), nullptr, nullptr, st);
     }
     // out = U^-1 L^-1 (dvec .* rhs)   (dvec == nullptr in M: plain M^-1 rhs, BiCGStab.zig:384-422)
-    void apply(const double2* rhs, double2* out, hipStream_t st) {
+    // times_d = false: plain M^-1 rhs whatever dvec the state was factorised with.  rhs == out is fine (a row reads its own right-hand side
+    // before it stores, and nothing else of rhs)
+    void apply(const double2* rhs, double2* out, hipStream_t st, bool times_d = true) {
+        const double2* keep = M.dvec;
+        if (!times_d) M.dvec = nullptr;
         run<ILU_FORWARD>(L, d_ordL.as<int32_t>(), d_ptrL.as<int32_t>(), rhs, out, st);
         run<ILU_BACKWARD>(U, d_ordU.as<int32_t>(), d_ptrU.as<int32_t>(), rhs, out, st);
+        M.dvec = keep;
     }
 };
 
@@ -473,6 +490,109 @@ extern "C" int tm_csr_solve(uint64_t n64, const int32_t* Ap, const int32_t* Ai, 
         hipLaunchKernelGGL(k_csr_bnorm, dim3(nwg), dim3(256), 0, st, n, d_b.as<double2>(), A.dinv, partials);
         HIPCHK(hipGetLastError());
         HIPCHK(launch_finalize_scalar(partials, nwg, red, S, STEP_TOL, st, opt.rtol, opt.atol));
+
+        if (opt.inner == TM_INNER_GMRES) {
+            // The reference's other Krylov solver in the slot (GMRES.zig:300-423; csrc/tm_gmres.hip for the kernels): restarted GMRES(30), LEFT
+            // preconditioned (GMRES.zig:335-336: z = M^-1 (A v)) with the diagonal -- the row-equilibrated operator the BiCGStab branch uses --
+            // or with ILU(0): M^-1 A v = M^-1 (D (D^-1 A v)), the substitution multiplying its right-hand side by the diagonal.  Stop test:
+            // GMRES's own residual norm |g_{j+1}| = ||P (b - A x)|| <= max(atol, rtol ||P b||), P the preconditioner (with the diagonal: the
+            // scale-aware test of every other path).
+            Dev d_W(vb), d_V(vb * (GMRES_M + 1)), d_G(sizeof(GmresScalars));
+            double2 *W = d_W.as<double2>(), *V = d_V.as<double2>();
+            GmresScalars* G = d_G.as<GmresScalars>();
+            HIPCHK(hipMemsetAsync(G, 0, sizeof(GmresScalars), st));
+            HIPCHK(hipMemsetAsync(V, 0, vb * (GMRES_M + 1), st));
+            auto Vk = [&](int k) { return V + static_cast<size_t>(k) * n; };
+            auto norm2_of = [&](const double2* v) {
+                hipLaunchKernelGGL(k_csr_norm2, dim3(nwg), dim3(256), 0, st, n, v, partials);
+                HIPCHK(hipGetLastError());
+                HIPCHK(launch_finalize(partials, nwg, red, st));
+            };
+            if (use_ilu) {
+                ilu->apply(d_b.as<double2>(), W, st, false);   // M^-1 b
+                norm2_of(W);
+            } else {
+                hipLaunchKernelGGL(k_csr_bnorm, dim3(nwg), dim3(256), 0, st, n, d_b.as<double2>(), A.dinv, partials);
+                HIPCHK(hipGetLastError());
+                HIPCHK(launch_finalize(partials, nwg, red, st));
+            }
+            HIPCHK(launch_gm_tol(G, red, opt.rtol, opt.atol, st));
+            GmresScalars h_G;
+            auto poll = [&]() {
+                HIPCHK(hipMemcpyAsync(&h_G, G, sizeof(GmresScalars), hipMemcpyDeviceToHost, st));
+                HIPCHK(hipStreamSynchronize(st));
+                return h_G.done[0] == 1 && h_G.done[1] == 1;
+            };
+            uint64_t it_total = 0;
+            bool converged = false, first = true;
+            double rr0[2] = {0.0, 0.0};
+            while (it_total < opt.max_inner) {
+                hipLaunchKernelGGL((k_csr_apply<true, DOT_OUT2>), dim3(nwg), dim3(256), 0, st, A, u, d_b.as<double2>(), nullptr, W, partials);   // D^-1 (b - A x)
+                HIPCHK(hipGetLastError());
+                if (use_ilu) {
+                    ilu->apply(W, W, st);   // M^-1 (b - A x)
+                    norm2_of(W);
+                } else {
+                    HIPCHK(launch_finalize(partials, nwg, red, st));
+                }
+                HIPCHK(launch_gm_begin(G, red, st));
+                const bool all_done = poll();
+                if (first) {
+                    rr0[0] = h_G.rr0[0];
+                    rr0[1] = h_G.rr0[1];
+                    first = false;
+                }
+                if (all_done) {
+                    converged = true;
+                    break;
+                }
+                HIPCHK(launch_gm_divide(Vk(0), W, G, n, st));
+                bool cycle_done = false;
+                for (int j = 0; j < GMRES_M && it_total < opt.max_inner; ++j) {
+                    hipLaunchKernelGGL((k_csr_apply<false, DOT_NONE>), dim3(nwg), dim3(256), 0, st, A, Vk(j), nullptr, nullptr, W, partials);   // D^-1 A v_j
+                    HIPCHK(hipGetLastError());
+                    if (use_ilu) ilu->apply(W, W, st);
+                    HIPCHK(launch_gm_mgs(W, nullptr, Vk(0), nullptr, G, 0, n, partials, st));
+                    HIPCHK(launch_finalize(partials, nwg_vec, red, st));
+                    for (int i = 1; i <= j; ++i) {
+                        HIPCHK(launch_gm_mgs(W, Vk(i - 1), Vk(i), red, G, i - 1, n, partials, st));
+                        HIPCHK(launch_finalize(partials, nwg_vec, red, st));
+                    }
+                    HIPCHK(launch_gm_mgs(W, Vk(j), nullptr, red, G, j, n, partials, st));
+                    HIPCHK(launch_finalize(partials, nwg_vec, red, st));
+                    HIPCHK(launch_gm_column(G, red, st));
+                    HIPCHK(launch_gm_divide(Vk(j + 1), W, G, n, st));
+                    it_total += 1;
+                    if ((j + 1) % static_cast<int>(opt.check_every) == 0 || j + 1 == GMRES_M || it_total == opt.max_inner) {
+                        if (poll()) {
+                            cycle_done = true;
+                            break;
+                        }
+                    }
+                }
+                HIPCHK(launch_gm_backsub(G, st));
+                HIPCHK(launch_gm_update(u, V, n, G, n, st));
+                if (cycle_done) {
+                    converged = true;
+                    break;
+                }
+            }
+            hipLaunchKernelGGL(k_deinterleave, dim3(nwg), dim3(256), 0, st, n, u, tmp, tmp + n);
+            HIPCHK(hipGetLastError());
+            HIPCHK(hipMemcpyAsync(x, tmp, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipMemcpyAsync(y, tmp + n, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+            HIPCHK(hipStreamSynchronize(st));
+            if (stats) {
+                std::memset(stats, 0, sizeof(*stats));
+                stats->outer_iterations = 1;
+                stats->inner_iterations = it_total;
+                stats->operator_sweeps = it_total + (it_total + GMRES_M - 1) / GMRES_M + 1;
+                stats->scaled_residual_rms = std::sqrt((rr0[0] + rr0[1]) / (2.0 * n));   // of P (b - A x0), P the preconditioner
+                stats->not_converged = converged ? 0 : 1;
+                stats->seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
+            return converged ? TM_OK : TM_W_NOT_CONVERGED;
+        }
 
         KrylovScalars h_S;
         auto read_S = [&]() {
