@@ -315,6 +315,17 @@ int tm_smoother_exchange_plan(const tm_smoother* s, int32_t* npeers, const int32
  * coordinates; scaled != 0 applies the row equilibration D^-1.  in/out are host arrays with
  * 2*dof doubles in global row order (smooth.zig:1643-1645).  Single-process handles only. */
 int tm_smoother_apply(tm_smoother* s, const double* in_xy, double* out_xy, int scaled);
+/* The system of the CURRENT device coordinates as the reference ASSEMBLES it -- RowCompressedMatrixSystem2d (smooth.zig:277-385: lhs_p,
+ * lhs_i in the reference's column order) filled by system.fill (smooth.zig:923-1113) on the device: interior rows StencilData.init's nine
+ * values in the reference's expression order (smooth.zig:171-216), perimeter rows from the plan; Ax_x / Ax_y = lhs_values after fillXSpecific
+ * / fillYSpecific (smooth.zig:1115-1165).  Ap [dof + 1], Ai / Ax_x / Ax_y [nnz]; any of them may be NULL (all NULL: *nnz only); the
+ * right-hand sides come from tm_smoother_rhs.  What a Zig caller gets from its own system.fill -- the arrays tm_csr_solve takes -- and what
+ * the parity tests compare with the faithful oracle bit for bit.  Single-process handles only. */
+int tm_smoother_assemble_csr(tm_smoother* s, int32_t* Ap, int32_t* Ai, double* Ax_x, double* Ax_y, uint64_t nnz_capacity, uint64_t* nnz);
+/* out = A(X) * in evaluated THROUGH that assembled system: every row the sum of its products in CSR order, un-fused -- the reference's own
+ * mat-vec (BiCGStab.zig:424-435) bit for bit, interior rows included.  (tm_smoother_apply is the matrix-free fast path: the same perimeter
+ * rows, interior rows in a factored form within 16 eps sum |c_k w_k| of this.)  Single-process handles only. */
+int tm_smoother_apply_reference_order(tm_smoother* s, const double* in_xy, double* out_xy);
 /* Right-hand side b (2*dof doubles) for the current coordinates (smooth.zig:780-921, 1060-1061). */
 int tm_smoother_rhs(tm_smoother* s, double* rhs_xy);
 /* Row kind per global row: -1 interior, else BlockBoundaryPointKind (smooth.zig:1168-1174). */

@@ -158,6 +158,12 @@ def test_4096_two_routes_to_the_same_picard_iterates():
     with smooth.Smoother(m0, solver.Option.hip()) as sm:
         got = sm.apply(w, scaled=False)
         kinds = sm.row_kinds()
+        # the device's OWN assembly of the reference's system (tm_smoother_assemble_csr: StencilData.init in reference order on every one of the
+        # 16.7 M rows) against the oracle's arrays: pattern and all 151 M coefficients bit for bit
+        Ap_d, Ai_d, Ax_d, _ = sm.assemble_csr()
+        assert np.array_equal(Ap_d, p) and np.array_equal(Ai_d, ci)
+        assert np.array_equal(Ax_d, v), f"{np.count_nonzero(Ax_d != v)} of {len(v)} coefficients differ"
+        del Ap_d, Ai_d, Ax_d
     ref = np.stack([A @ w[:, 0], A @ w[:, 1]], axis=1)
     perim = kinds >= 0
     assert np.array_equal(got[perim], ref[perim])

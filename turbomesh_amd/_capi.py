@@ -116,7 +116,7 @@ EXPORTS = [
     "tm_smoother_exchange_plan", "tm_smoother_apply", "tm_smoother_rhs", "tm_smoother_row_kinds", "tm_smoother_dof",
     "tm_smoother_control_function", "tm_smoother_profile", "tm_smoother_profile_read", "tm_plan_build", "tm_plan_free", "tm_plan_local", "tm_plan_local_free", "tm_dev_tfi_block", "tm_dev_relax_sweep",
     "tm_dev_relax_partials_needed", "tm_export_soa", "tm_smoother_export_soa", "tm_rccl_unique_id", "tm_rccl_comm_create", "tm_rccl_comm_destroy", "tm_rccl_hooks",
-    "tm_rccl_peer_table_build", "tm_rccl_peer_table_free", "tm_white_math_probe", "tm_stream_probe", "tm_smoother_queue_ordering", "tm_smoother_inner", "tm_csr_ilu0_probe", "tm_rccl_hooks_for",
+    "tm_rccl_peer_table_build", "tm_rccl_peer_table_free", "tm_white_math_probe", "tm_stream_probe", "tm_smoother_queue_ordering", "tm_smoother_inner", "tm_csr_ilu0_probe", "tm_rccl_hooks_for", "tm_smoother_assemble_csr", "tm_smoother_apply_reference_order",
 ]
 
 _lib = None
@@ -181,6 +181,8 @@ def lib():
         L.tm_smoother_exchange_plan.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.POINTER(C.c_int32))] + [C.POINTER(C.POINTER(C.c_int64))] * 4
         L.tm_smoother_apply.argtypes = [C.c_void_p, _dp, _dp, C.c_int]
         L.tm_smoother_rhs.argtypes = [C.c_void_p, _dp]
+        L.tm_smoother_assemble_csr.argtypes = [C.c_void_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), _dp, _dp, C.c_uint64, C.POINTER(C.c_uint64)]
+        L.tm_smoother_apply_reference_order.argtypes = [C.c_void_p, _dp, _dp]
         L.tm_smoother_row_kinds.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
         L.tm_smoother_control_function.argtypes = [C.c_void_p, _dp]
         L.tm_smoother_profile.argtypes = [C.c_void_p, C.c_int]

@@ -347,6 +347,21 @@ int tm_smoother_apply(tm_smoother* s, const double* in_xy, double* out_xy, int s
         return TM_OK;
     });
 }
+int tm_smoother_assemble_csr(tm_smoother* s, int32_t* Ap, int32_t* Ai, double* Ax_x, double* Ax_y, uint64_t nnz_capacity, uint64_t* nnz) {
+    return guarded([&]() {
+        if (!s) throw TmError(TM_E_ARG, "null handle");
+        const uint64_t n = s->impl.assemble_csr_host(Ap, Ai, Ax_x, Ax_y, nnz_capacity);
+        if (nnz) *nnz = n;
+        return TM_OK;
+    });
+}
+int tm_smoother_apply_reference_order(tm_smoother* s, const double* in_xy, double* out_xy) {
+    return guarded([&]() {
+        if (!s || !in_xy || !out_xy) throw TmError(TM_E_ARG, "null argument");
+        s->impl.apply_reference_host(in_xy, out_xy);
+        return TM_OK;
+    });
+}
 int tm_smoother_rhs(tm_smoother* s, double* rhs_xy) {
     return guarded([&]() {
         if (!s || !rhs_xy) throw TmError(TM_E_ARG, "null argument");

@@ -224,6 +224,16 @@ hipError_t launch_queue_wait(const uint32_t* counter, uint32_t target, uint32_t*
 hipError_t launch_queue_signal_wait(uint32_t* counter, const uint32_t* other, uint32_t target, uint32_t* error, hipStream_t stream,
                                     long long limit_ticks = QUEUE_WAIT_TICKS);
 
+// ---- the reference's ASSEMBLED system on the device (RowCompressedMatrixSystem2d values, smooth.zig:923-1113), for the introspection entry
+// points tm_smoother_assemble_csr / tm_smoother_apply_reference_order: row_ptr = the CSR row pointers of the rank-local rows (host-built
+// from the plan); interior rows get StencilData.init's nine values in ascending column order (smooth.zig:171-216, 923-992: stencil_coefs,
+// the reference's expression order), perimeter rows their static coefficients or -- smoothed rows -- the same nine values by slot
+hipError_t launch_assemble_interior(const double2* xk, const double2* pq, int ni, int nj, const int32_t* row_ptr /* of the block's node (0,0) */,
+                                    double* vx, double* vy, hipStream_t stream);
+hipError_t launch_assemble_edge(const EdgeRowsDev& e, const double2* xk, const double2* pq, const int32_t* row_ptr, double* vx, double* vy, hipStream_t stream);
+// out = A in, the sum of a row's products in CSR order, un-fused and unscaled: BiCGStab.zig:424-435 bit for bit
+hipError_t launch_csr_product(int64_t n, const int32_t* row_ptr, const int32_t* col, const double* vx, const double* vy, const double2* in, double2* out,
+                              hipStream_t stream);
 hipError_t launch_delay_us(double us, hipStream_t stream);   // measurement support: a one-wave kernel that lasts `us` microseconds
 
 // ---- reductions: sum partial rows [nwg][MAX_PARTIALS] in fixed order into red[MAX_PARTIALS]

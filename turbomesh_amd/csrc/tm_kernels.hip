@@ -2334,6 +2334,93 @@ hipError_t launch_queue_signal_wait(uint32_t* counter, const uint32_t* other, ui
     hipLaunchKernelGGL(k_queue_signal_wait, dim3(1), dim3(64), 0, st, counter, other, target, error, limit_ticks);
     return hipGetLastError();
 }
+// ------------------------------------------------------------------------------------------
+// The assembled system (introspection: tm_smoother_assemble_csr, tm_smoother_apply_reference_order)
+// ------------------------------------------------------------------------------------------
+template <bool HAS_PQ>
+__global__ __launch_bounds__(256) void k_assemble_interior(const double2* __restrict__ xk, const double2* __restrict__ pq, int ni, int nj,
+                                                           const int32_t* __restrict__ row_ptr, double* __restrict__ vx, double* __restrict__ vy) {
+    const int j = blockIdx.x * 256 + threadIdx.x;
+    if (j < 1 || j > nj - 2) return;
+    for (int i = 1 + static_cast<int>(blockIdx.y); i <= ni - 2; i += gridDim.y) {
+        const size_t at = static_cast<size_t>(i) * nj + j;
+        double c[9];
+        const double2 cf = HAS_PQ ? pq[at] : make_double2(0.0, 0.0);
+        stencil_coefs<HAS_PQ>(xk[at - nj], xk[at + nj], xk[at - 1], xk[at + 1], cf.x, cf.y, c);   // im1_j, ip1_j, i_jm1, i_jp1; (P, Q): smooth.zig:936-945
+        const int e = row_ptr[at];
+        // ascending column id = (i-1, j-1..j+1), (i, j-1..j+1), (i+1, j-1..j+1): smooth.zig:946-955
+        const double v[9] = {c[S_IM1_JM1], c[S_IM1_J], c[S_IM1_JP1], c[S_I_JM1], c[S_I_J], c[S_I_JP1], c[S_IP1_JM1], c[S_IP1_J], c[S_IP1_JP1]};
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            vx[e + q] = v[q];
+            vy[e + q] = v[q];
+        }
+    }
+}
+hipError_t launch_assemble_interior(const double2* xk, const double2* pq, int ni, int nj, const int32_t* row_ptr, double* vx, double* vy, hipStream_t st) {
+    if (ni < 3 || nj < 3) return hipSuccess;
+    const dim3 grid((nj + 255) / 256, std::min(ni - 2, 4096));
+    if (pq) hipLaunchKernelGGL(k_assemble_interior<true>, grid, dim3(256), 0, st, xk, pq, ni, nj, row_ptr, vx, vy);
+    else hipLaunchKernelGGL(k_assemble_interior<false>, grid, dim3(256), 0, st, xk, pq, ni, nj, row_ptr, vx, vy);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(EDGE_BLOCK) void k_assemble_edge(EdgeRowsDev e, const double2* __restrict__ xk, const double2* __restrict__ pq,
+                                                              const int32_t* __restrict__ row_ptr, double* __restrict__ vx, double* __restrict__ vy) {
+    const EdgeRun& R = e.runs[__builtin_amdgcn_readfirstlane(e.wg_run[blockIdx.x])];
+    const int k = __builtin_amdgcn_readfirstlane(e.wg_k0[blockIdx.x]) + static_cast<int>(threadIdx.x);
+    if (k >= R.count) return;
+    const int row = R.row0 + k * R.row_stride;
+    const int e0 = row_ptr[row];
+    if (R.kind == 1 /* smoothed */) {   // as edge_row_eval: smooth.zig:1029-1084
+        const double2 im1_j = xk[R.met0[0] + k * R.met_stride[0]], ip1_j = xk[R.met0[1] + k * R.met_stride[1]];
+        const double2 i_jm1 = xk[R.met0[2] + k * R.met_stride[2]];
+        double2 i_jp1 = xk[R.met0[3] + k * R.met_stride[3]];
+        const bool periodic = R.flags & 1;
+        if (periodic) {
+            i_jp1.x = i_jp1.x + (-R.per[0]);
+            i_jp1.y = i_jp1.y + (-R.per[1]);
+        }
+        const double2 cf = pq ? pq[row] : make_double2(0.0, 0.0);
+        const double P = periodic ? cf.x : cf.y, Q = periodic ? cf.y : cf.x;
+        double c[9];
+        stencil_coefs<true>(im1_j, ip1_j, i_jm1, i_jp1, P, Q, c);
+#pragma unroll
+        for (int q = 0; q < 9; ++q) {
+            const double ck = pick9(c, R.slot[q]);
+            vx[e0 + q] = ck;
+            vy[e0 + q] = ck;
+        }
+        return;
+    }
+#pragma unroll
+    for (int q = 0; q < 9; ++q)
+        if (q < R.ncols) {
+            vx[e0 + q] = R.cx[q];
+            vy[e0 + q] = R.cy[q];
+        }
+}
+hipError_t launch_assemble_edge(const EdgeRowsDev& e, const double2* xk, const double2* pq, const int32_t* row_ptr, double* vx, double* vy, hipStream_t st) {
+    if (e.nrows == 0) return hipSuccess;
+    hipLaunchKernelGGL(k_assemble_edge, dim3(e.nwg), dim3(EDGE_BLOCK), 0, st, e, xk, pq, row_ptr, vx, vy);
+    return hipGetLastError();
+}
+__global__ __launch_bounds__(256) void k_csr_product(int64_t n, const int32_t* __restrict__ row_ptr, const int32_t* __restrict__ col, const double* __restrict__ vx,
+                                                     const double* __restrict__ vy, const double2* __restrict__ in, double2* __restrict__ out) {
+    const int64_t row = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (row >= n) return;
+    double sx = 0.0, sy = 0.0;
+    for (int k = row_ptr[row]; k < row_ptr[row + 1]; ++k) {   // sum += lhs_values[k] * x[lhs_i[k]], BiCGStab.zig:424-435
+        const double2 w = in[col[k]];
+        sx += vx[k] * w.x;
+        sy += vy[k] * w.y;
+    }
+    out[row] = make_double2(sx, sy);
+}
+hipError_t launch_csr_product(int64_t n, const int32_t* row_ptr, const int32_t* col, const double* vx, const double* vy, const double2* in, double2* out, hipStream_t st) {
+    hipLaunchKernelGGL(k_csr_product, dim3(static_cast<unsigned>((n + 255) / 256)), dim3(256), 0, st, n, row_ptr, col, vx, vy, in, out);
+    return hipGetLastError();
+}
+
 // measurement support (libtm_hip_dbg.so's null transport): one wave that keeps its queue busy for `us` microseconds of the constant
 // 100 MHz clock -- the device time of a halo exchange that moves nothing, so that a rank's schedule can be timed with the exchange
 // ON its chain without peers

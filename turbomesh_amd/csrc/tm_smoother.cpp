@@ -141,6 +141,7 @@ Smoother::~Smoother() {
         (void)hipStreamDestroy(side);
     }
     if (export_buf) (void)hipFree(export_buf);
+    csr_release();
 }
 
 // ------------------------------------------------------------------ create
@@ -1905,6 +1906,96 @@ void Smoother::apply_host(const double* in_xy, double* out_xy, int scaled) {
     apply(tmpA, tmpB, scaled ? MODE_SCALED : MODE_RAW, DOT_NONE, nullptr, X, 0.0);
     HIPCHK(hipMemcpyAsync(out_xy, tmpB, sizeof(double2) * n_owned, hipMemcpyDeviceToHost, stream));
     sync();
+}
+
+// ---- the reference's assembled system on the device (introspection).  Pattern: RowCompressedMatrixSystem2d.init (smooth.zig:309-385) --
+// interior rows nine columns in ascending id, perimeter rows the plan's columns (ascending global id = the reference's order); values:
+// system.fill for the CURRENT coordinates (smooth.zig:923-1113) by k_assemble_interior / k_assemble_edge, x and y systems (they differ in
+// the sliding rows, smooth.zig:1115-1165).
+void Smoother::csr_build_pattern() {
+    if (has_hooks) throw TmError(TM_E_UNSUPPORTED, "the assembled system is available on single-process handles only");
+    if (!csr.h_p.empty()) return;
+    const int64_t n = n_owned;
+    std::vector<int32_t> count(static_cast<size_t>(n), 9);
+    std::vector<const PlanRow*> perim(static_cast<size_t>(n), nullptr);
+    for (const PlanRow& pr : lp.rows) {
+        const int64_t l = lp.to_local(pr.gid);
+        if (l < 0 || l >= n) throw TmError(TM_E_TOPOLOGY, "internal: perimeter row outside the owned rows");
+        count[l] = pr.ncols;
+        perim[l] = &pr;
+    }
+    uint64_t nnz = 0;
+    for (int64_t r = 0; r < n; ++r) nnz += static_cast<uint64_t>(count[r]);
+    if (nnz >= (uint64_t{1} << 31)) throw TmError(TM_E_SIZE, "the assembled system has more than 2^31 non-zeros");
+    csr.h_p.resize(static_cast<size_t>(n) + 1);
+    csr.h_i.resize(nnz);
+    int32_t at = 0;
+    for (size_t kb = 0; kb < lp.owned_blocks.size(); ++kb) {
+        const int64_t b = lp.owned_blocks[kb], ls = lp.local_start[kb], bj = topo.nj[b];
+        const int64_t nb = topo.ni[b] * bj;
+        for (int64_t f = 0; f < nb; ++f) {
+            const int64_t r = ls + f;
+            csr.h_p[r] = at;
+            if (const PlanRow* pr = perim[r]) {
+                for (int q = 0; q < pr->ncols; ++q) csr.h_i[at++] = static_cast<int32_t>(lp.to_local(pr->col[q]));
+            } else {
+                for (int64_t di = -1; di <= 1; ++di)
+                    for (int64_t dj = -1; dj <= 1; ++dj) csr.h_i[at++] = static_cast<int32_t>(r + di * bj + dj);
+            }
+        }
+    }
+    csr.h_p[n] = at;
+    csr.nnz = nnz;
+}
+
+void Smoother::csr_release() {
+    for (void* q : {static_cast<void*>(csr.p), static_cast<void*>(csr.i), static_cast<void*>(csr.vx), static_cast<void*>(csr.vy)})
+        if (q) (void)hipFree(q);
+    csr.p = csr.i = nullptr;
+    csr.vx = csr.vy = nullptr;
+}
+
+void Smoother::csr_fill_values() {
+    csr_build_pattern();
+    if (!csr.p) {
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&csr.p), sizeof(int32_t) * csr.h_p.size()));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&csr.i), sizeof(int32_t) * std::max<size_t>(1, csr.h_i.size())));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&csr.vx), sizeof(double) * std::max<uint64_t>(1, csr.nnz)));
+        HIPCHK(hipMalloc(reinterpret_cast<void**>(&csr.vy), sizeof(double) * std::max<uint64_t>(1, csr.nnz)));
+        HIPCHK(hipMemcpyAsync(csr.p, csr.h_p.data(), sizeof(int32_t) * csr.h_p.size(), hipMemcpyHostToDevice, stream));
+        HIPCHK(hipMemcpyAsync(csr.i, csr.h_i.data(), sizeof(int32_t) * csr.h_i.size(), hipMemcpyHostToDevice, stream));
+    }
+    for (size_t kb = 0; kb < lp.owned_blocks.size(); ++kb) {
+        const int64_t b = lp.owned_blocks[kb], ls = lp.local_start[kb];
+        HIPCHK(launch_assemble_interior(X + ls, PQ ? PQ + ls : nullptr, static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), csr.p + ls, csr.vx, csr.vy, stream));
+    }
+    HIPCHK(launch_assemble_edge(edge, X, PQ, csr.p, csr.vx, csr.vy, stream));
+}
+
+uint64_t Smoother::assemble_csr_host(int32_t* Ap, int32_t* Ai, double* Ax_x, double* Ax_y, uint64_t nnz_capacity) {
+    csr_build_pattern();
+    if (!Ap && !Ai && !Ax_x && !Ax_y) return csr.nnz;   // size query
+    if (Ap) std::memcpy(Ap, csr.h_p.data(), sizeof(int32_t) * csr.h_p.size());
+    if ((Ai || Ax_x || Ax_y) && nnz_capacity < csr.nnz) throw TmError(TM_E_SIZE, "nnz_capacity is smaller than the system's non-zero count");
+    if (Ai) std::memcpy(Ai, csr.h_i.data(), sizeof(int32_t) * csr.h_i.size());
+    if (Ax_x || Ax_y) {
+        csr_fill_values();
+        if (Ax_x) HIPCHK(hipMemcpyAsync(Ax_x, csr.vx, sizeof(double) * csr.nnz, hipMemcpyDeviceToHost, stream));
+        if (Ax_y) HIPCHK(hipMemcpyAsync(Ax_y, csr.vy, sizeof(double) * csr.nnz, hipMemcpyDeviceToHost, stream));
+        sync();
+        csr_release();
+    }
+    return csr.nnz;
+}
+
+void Smoother::apply_reference_host(const double* in_xy, double* out_xy) {
+    ensure_tmp();
+    csr_fill_values();
+    HIPCHK(hipMemcpyAsync(tmpA, in_xy, sizeof(double2) * n_owned, hipMemcpyHostToDevice, stream));
+    HIPCHK(launch_csr_product(n_owned, csr.p, csr.i, csr.vx, csr.vy, tmpA, tmpB, stream));
+    HIPCHK(hipMemcpyAsync(out_xy, tmpB, sizeof(double2) * n_owned, hipMemcpyDeviceToHost, stream));
+    sync();
+    csr_release();
 }
 
 void Smoother::rhs_host(double* rhs_xy) {

@@ -158,6 +158,19 @@ struct Smoother {
     bool iterate_until_update(uint64_t max_iterations, double tol, tm_stats* stats);   // true = the update of the last outer iteration was <= tol
     double stop_tol = 0.0;          // > 0: a Picard iteration whose start residual is already <= stop_tol returns without solving
     void apply_host(const double* in_xy, double* out_xy, int scaled);
+    // the reference's assembled system for the current coordinates (tm_smoother_assemble_csr) and A in through it, in CSR order
+    // (tm_smoother_apply_reference_order); single-process handles
+    uint64_t assemble_csr_host(int32_t* Ap, int32_t* Ai, double* Ax_x, double* Ax_y, uint64_t nnz_capacity);
+    void apply_reference_host(const double* in_xy, double* out_xy);
+    struct AssembledCsr {            // device copy, built on demand, dropped by the next iterate / upload
+        int32_t *p = nullptr, *i = nullptr;
+        double *vx = nullptr, *vy = nullptr;
+        uint64_t nnz = 0;
+        std::vector<int32_t> h_p, h_i;
+    } csr;
+    void csr_build_pattern();
+    void csr_fill_values();
+    void csr_release();
     void rhs_host(double* rhs_xy);
     void control_function_host(double* pq);
     void export_soa_host(int64_t block, double* x, double* y, double* p, double* q);

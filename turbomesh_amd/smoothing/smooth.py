@@ -135,6 +135,25 @@ class Smoother:
         _capi.check(_capi.lib().tm_smoother_apply(self._h, _capi.f64ptr(vec), _capi.f64ptr(out), 1 if scaled else 0))
         return out
 
+    def assemble_csr(self):
+        """The reference's assembled system for the current device coordinates (tm_smoother_assemble_csr): (Ap, Ai, Ax_x, Ax_y)."""
+        n = C.c_uint64(0)
+        _capi.check(_capi.lib().tm_smoother_assemble_csr(self._h, None, None, None, None, 0, C.byref(n)))
+        nnz = int(n.value)
+        Ap, Ai = np.empty(self.dof + 1, dtype=np.int32), np.empty(nnz, dtype=np.int32)
+        Ax, Ay = np.empty(nnz), np.empty(nnz)
+        ip = C.POINTER(C.c_int32)
+        _capi.check(_capi.lib().tm_smoother_assemble_csr(self._h, Ap.ctypes.data_as(ip), Ai.ctypes.data_as(ip), _capi.f64ptr(Ax), _capi.f64ptr(Ay), nnz, C.byref(n)))
+        return Ap, Ai, Ax, Ay
+
+    def apply_reference_order(self, vec):
+        """out = A(X) vec through the assembled system, rows summed in CSR order (the reference's mat-vec, bit for bit)."""
+        vec = np.ascontiguousarray(vec, dtype=np.float64)
+        assert vec.shape == (self.dof, 2)
+        out = np.empty_like(vec)
+        _capi.check(_capi.lib().tm_smoother_apply_reference_order(self._h, _capi.f64ptr(vec), _capi.f64ptr(out)))
+        return out
+
     def rhs(self):
         out = np.empty((self.dof, 2))
         _capi.check(_capi.lib().tm_smoother_rhs(self._h, _capi.f64ptr(out)))
