@@ -375,16 +375,16 @@ def main():
             flag = torch.tensor([ok], dtype=torch.int32, device=flag_dev)
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if int(flag.item()) == 1:
-                # the check runs the schedule of the timed region: with TM_TRIPLES_MIN_NODES=1 (read at every plan build) the small strip
-                # takes the depth-3 halo and the coupled sweep triples of the 2048^2 / 4096^2 blocks, 9 sweeps = three triples; then 4
-                # more through the pair schedule (depth-2 exchange lists)
+                # the check runs the schedules of the timed region on a small strip: 9 sweeps = three coupled sweep triples (depth-3 halo, one
+                # exchange per triple, the fused level kernel), then -- library defaults -- 5 sweeps = a triple and the PAIR that takes the
+                # remainder of a sweep count that is not a multiple of three (its exchange, its border pass)
                 saved_min = os.environ.get("TM_TRIPLES_MIN_NODES")
                 try:
                     # one handle at a time: a process with a single multi-rank handle orders its two queues with counters in
                     # device memory (the schedule of the timed run); two live handles would both fall back to events
                     small = [tmd.strip_for_rank(world, rank, 192, 256, blocks_per_rank=bpr) for _ in range(2)]
                     ok = 1
-                    for min_nodes, sweeps in (("1", 9), (None, 4)):
+                    for min_nodes, sweeps in (("1", 9), (None, 5)):
                         if min_nodes is None:
                             os.environ.pop("TM_TRIPLES_MIN_NODES", None)
                             if saved_min is not None:
