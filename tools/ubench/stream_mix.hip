@@ -105,6 +105,23 @@ int main(int argc, char** argv) {
     mix<2, 1>("triad", A, n);
     mix<4, 1>("k_apply_vk<VK_S2>'s mix (r, v, frozen field, r_hat -> t)", A, n);
     mix<7, 4>("k_apply_vk<VK_R>'s mix (r, v, t, p, u, frozen field, r_hat -> r', p', v', u)", A, n);
+    // Do the arrays' relative positions matter?  (Same index in every array = same low address bits when the arrays lie a multiple of
+    // 256 MiB apart: the channel / bank a workgroup's 11 requests of one trip map to.)  One slab, array k at k * (256 MiB + pad).
+    {
+        const long pads[] = {0, 256, 4096, 4096 + 256, 65536 + 4096 + 256, (1 << 20) + 65536 + 4096 + 256, 3 * 65536 + 3 * 4096 + 768};
+        char* slab; CK(hipMalloc(&slab, 11 * (16 * n + (2 << 20))));
+        CK(hipMemset(slab, 0, 11 * (16 * n + (2 << 20))));
+        for (long pad : pads) {
+            Arrays B;
+            for (int k = 0; k < 11; ++k) B.p[k] = reinterpret_cast<d2v*>(slab + k * (16 * n + pad));
+            B.p[11] = nullptr;
+            printf("one slab, arrays %ld MiB + %ld B apart\n", mib, pad);
+            run<7, 4, 2>(B, n, 8192);
+            run<7, 4, 2>(B, n, 1024);
+            run<4, 1, 1>(B, n, 2048);
+        }
+        CK(hipFree(slab));
+    }
     printf("the same mixes as fewer, wider streams (256 MiB per array, 32 B per lane)\n");
     for (int grid : {1024, 2048, 8192}) run_wide<2, 1>(A, n / 2, grid);   // ~ VK_S2 with (r, v) side by side: 4 x 16 B read, 2 x 16 B written
     for (int grid : {1024, 2048, 8192}) run_wide<4, 2>(A, n / 2, grid);   // ~ VK_R: 8 x 16 B read, 4 x 16 B written in 6 streams
