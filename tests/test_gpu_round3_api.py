@@ -172,6 +172,47 @@ def test_inner_auto_is_decided_by_the_largest_block():
     assert float(np.sqrt(np.mean((a.blocks[0].points.data - b.blocks[0].points.data) ** 2))) <= 1e-10
 
 
+def test_inner_auto_keeps_the_plain_solve_on_boundary_layer_clustering():
+    # round 4: a block-wide point-Jacobi cycle is a poor preconditioner where the cells' aspect ratio varies strongly inside a block (the
+    # reference's O-grids refined to 10^5..10^6 nodes: tools/dev/o4h_auto_probe.py); a single-process handle reads that off the coordinates
+    import json, os
+
+    from turbomesh_amd import clustering, configs
+    from turbomesh_amd.input import Input
+    from turbomesh_amd.smoothing import smooth, solver
+
+    auto = solver.Option.hip(inner=solver.Inner.auto)
+    n = 400
+    # a rectangle with wall clustering in j (first cell 1e-4 of the height): aspect ratios from ~600 at the wall to ~0.2 at the far side
+    mesh = configs.single_block(n, n)
+    y = clustering.SingleHyperbolicClustering(1e-4).compute(n)
+    d = mesh.blocks[0].points.data
+    d[..., 0] = np.linspace(0.0, 1.0, n)[:, None]
+    d[..., 1] = y[None, :]
+    with smooth.Smoother(mesh, auto) as sm:
+        assert sm.inner == solver.Inner.bicgstab
+    # the same block stretched UNIFORMLY (every cell 50 : 1) is what the semi-coarsening is for: the cycle stays
+    mesh = configs.single_block(n, n)
+    d = mesh.blocks[0].points.data
+    d[..., 0] = np.linspace(0.0, 50.0, n)[:, None]
+    d[..., 1] = np.linspace(0.0, 1.0, n)[None, :]
+    with smooth.Smoother(mesh, auto) as sm:
+        assert sm.inner == solver.Inner.mg_bicgstab
+    # the T106 example refined 8 x (blocks up to 308 481 nodes, O-grid clustering): plain solve; an explicit choice is kept
+    gold = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    j = json.load(open(os.path.join(gold, "examples", "T106", "T106.json")))
+    nc = j["template"]["O4H"]["num_cells"]
+    for k in nc:
+        nc[k] *= 2 if k == "o_grid" else 8
+    inp = Input.parse(json.dumps(j))
+    mesh = inp.template.run(inp.geometry(gold))
+    assert max(b.points.size[0] * b.points.size[1] for b in mesh.blocks) >= 100000
+    with smooth.Smoother(mesh, auto, inp.wall_control_function) as sm:
+        assert sm.inner == solver.Inner.bicgstab
+    with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab), inp.wall_control_function) as sm:
+        assert sm.inner == solver.Inner.mg_bicgstab
+
+
 def test_a_handle_that_never_runs_triples_exchanges_the_depth_2_halo_only(monkeypatch):
     # the depth-3 ghost set (one exchange per sweep TRIPLE) used to be exchanged by every handle on large blocks, Krylov modes
     # included.  Now the depth follows the handle's options -- identical on every rank -- and the library's own transport builds its tables

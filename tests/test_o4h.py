@@ -180,7 +180,7 @@ def test_cli_runs_the_t106_input_with_the_hip_solver(tmp_path):
     assert r.returncode == 0, r.stderr
     # --hip without a strategy = auto: on these blocks (<= 9061 nodes) that is the plain Picard + BiCGStab solve (7x faster here than the
     # multigrid-preconditioned one); the program says which one it took
-    assert "inner strategy: bicgstab (chosen from the block sizes)" in r.stderr, r.stderr[-2000:]
+    assert "inner strategy: bicgstab (chosen from the block sizes" in r.stderr, r.stderr[-2000:]
     blocks = output.read_plot3d(out)
     assert [(b[0], b[1]) for b in blocks] == [(221, 41), (121, 41), (11, 41), (11, 51), (121, 41), (161, 11), (21, 91), (11, 131)]
     # --hip file: the solver the JSON names ("gmres" + "ilu0", examples/T106/T106.json:28-41) honoured by its device counterpart -- GMRES(30) as

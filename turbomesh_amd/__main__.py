@@ -6,7 +6,8 @@ The example inputs name the reference's own solvers ("gmres" + "ilu0"), which st
 without UMFPACK answers error.ExternalSolverNotEnabled, this program refuses them -- unless --hip replaces the solver entry
 by {"hip": {"inner": "auto"}} (what a user would write into the JSON): the plain Picard + BiCGStab solve on meshes of small blocks
 like the reference's examples (T106 / LS89: 7x faster there than the multigrid-preconditioned one), the multigrid-preconditioned
-solve once a block has 100 000 nodes or more."""
+solve once a block has 100 000 nodes or more and the cells' aspect ratio does not vary strongly inside any block (refined O-grids with
+boundary-layer clustering keep the plain solve)."""
 from __future__ import annotations
 
 import argparse
@@ -47,7 +48,7 @@ def main(argv=None):
     iterations = inp.iterations if args.iterations is None else args.iterations
     slog = logging.getLogger("smoothing")
     with smooth.per_iteration_log(slog.isEnabledFor(logging.INFO) and not args.until), smooth.Smoother(mesh, inp.solver, inp.wall_control_function) as sm:
-        slog.info("hip solver, inner strategy: %s%s", sm.inner.name, " (chosen from the block sizes)" if inp.solver.inner == solver.Inner.auto else "")
+        slog.info("hip solver, inner strategy: %s%s", sm.inner.name, " (chosen from the block sizes and the spread of the cells' aspect ratios)" if inp.solver.inner == solver.Inner.auto else "")
         if args.until:
             reached, stats = sm.iterate_until(args.until, iterations or 100)
             slog.info("scaled residual %.3e after %d iterations (%s)", stats["scaled_residual_rms"], stats["outer_iterations"], "reached" if reached else "NOT reached")

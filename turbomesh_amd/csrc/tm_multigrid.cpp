@@ -10,10 +10,13 @@ namespace tmh {
 
 #define HIPCHK(x) hip_check((x), #x)
 
-double BlockMG::aspect_of(const double* xy, int ni, int nj) {
-    if (!xy || ni < 3 || nj < 3) return 1.0;
-    const int si = std::max(1, (ni - 2) / 64), sj = std::max(1, (nj - 2) / 64);   // ~4096 samples
-    double sum = 0.0;
+// log(g11 / g22) over ~4096 interior nodes of the caller's coordinates: its mean (-> the block's mean cell aspect ratio, which the
+// semi-coarsening follows) and its standard deviation (what NO block-wide coarsening rule follows: TM_INNER_AUTO, tm_smoother.cpp)
+static void log_aspect_stats(const double* xy, int ni, int nj, double& mean, double& sdev) {
+    mean = sdev = 0.0;
+    if (!xy || ni < 3 || nj < 3) return;
+    const int si = std::max(1, (ni - 2) / 64), sj = std::max(1, (nj - 2) / 64);
+    double sum = 0.0, sum2 = 0.0;
     long cnt = 0;
     for (int i = 1; i < ni - 1; i += si)
         for (int j = 1; j < nj - 1; j += sj) {
@@ -22,11 +25,27 @@ double BlockMG::aspect_of(const double* xy, int ni, int nj) {
             const double bx = c[2] - c[-2], by = c[3] - c[-1];
             const double g11 = ax * ax + ay * ay, g22 = bx * bx + by * by;
             if (g11 > 0.0 && g22 > 0.0) {
-                sum += std::log(g11 / g22);
+                const double l = std::log(g11 / g22);
+                sum += l;
+                sum2 += l * l;
                 cnt += 1;
             }
         }
-    return cnt ? std::exp(sum / static_cast<double>(cnt)) : 1.0;
+    if (!cnt) return;
+    mean = sum / static_cast<double>(cnt);
+    sdev = std::sqrt(std::max(0.0, sum2 / static_cast<double>(cnt) - mean * mean));
+}
+
+double BlockMG::aspect_of(const double* xy, int ni, int nj) {
+    double mean, sdev;
+    log_aspect_stats(xy, ni, nj, mean, sdev);
+    return std::exp(mean);
+}
+
+double BlockMG::aspect_spread_of(const double* xy, int ni, int nj) {
+    double mean, sdev;
+    log_aspect_stats(xy, ni, nj, mean, sdev);
+    return sdev;
 }
 
 void BlockMG::build(DeviceArena& arena, int ni, int nj, bool has_pq, double aspect, bool worst_case) {

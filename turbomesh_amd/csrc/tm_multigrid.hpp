@@ -37,6 +37,7 @@ class BlockMG {
     // aspect = mean g11/g22 of the block's cells (1 = unknown / isotropic); worst_case = size the arena for any aspect
     void build(DeviceArena& arena, int ni, int nj, bool has_pq, double aspect, bool worst_case);
     static double aspect_of(const double* xy, int ni, int nj);   // host estimate from the caller's coordinates
+    static double aspect_spread_of(const double* xy, int ni, int nj);   // standard deviation of log(g11/g22) over the same samples (0 = unknown / uniform)
     // refresh the level hierarchy from the fine frozen field (after every change of X / PQ)
     void set_field(const double2* X0, const double2* PQ0, hipStream_t stream);
     // z = V-cycle(f).  w0, w1: two fine scratch blocks whose perimeter is and stays zero.  z's perimeter is left zero.

@@ -159,7 +159,17 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         uint64_t largest = 0;
         if (mesh && mesh->blocks)
             for (uint64_t b = 0; b < mesh->nblocks; ++b) largest = std::max<uint64_t>(largest, mesh->blocks[b].ni * mesh->blocks[b].nj);
-        opt.inner = largest >= AUTO_MG_MIN_BLOCK_NODES ? TM_INNER_MG_BICGSTAB : TM_INNER_BICGSTAB;
+        bool cycle = largest >= AUTO_MG_MIN_BLOCK_NODES;
+        // ... and cells whose aspect ratio does not vary much inside a block.  Read off the caller's coordinates, which only a single-process
+        // handle is sure to have for every block (the ranks of a job must decide alike, so with hooks the sizes decide alone; so does
+        // the sizing call, whose answer has to cover whatever create decides later)
+        const bool ranks = h != nullptr && h->nranks >= 1 && h->exchange != nullptr && h->allreduce_sum != nullptr;
+        if (cycle && !ranks && !measure && mesh && mesh->blocks)
+            for (uint64_t b = 0; b < mesh->nblocks && cycle; ++b)
+                if (mesh->blocks[b].ni * mesh->blocks[b].nj >= 1024 &&
+                    BlockMG::aspect_spread_of(mesh->blocks[b].xy, static_cast<int>(mesh->blocks[b].ni), static_cast<int>(mesh->blocks[b].nj)) > AUTO_MG_MAX_ASPECT_SPREAD)
+                    cycle = false;
+        opt.inner = cycle ? TM_INNER_MG_BICGSTAB : TM_INNER_BICGSTAB;
     }
     if (!(opt.atol > 0)) opt.atol = 0.0;
     if (opt.check_every == 0) opt.check_every = (opt.inner == TM_INNER_MG_BICGSTAB) ? 1 : 8;   // a multigrid-preconditioned iteration costs ~100x a poll
