@@ -608,13 +608,32 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     // the per-block rule of tm_kernels.hip (apply_rows = 0)
     const int edge_wg = (opt.inner == TM_INNER_RELAX ? edge_nf.nwg : edge.nwg);   // a relax handle only ever launches the non-fixed rows
     apply_rows = 0;
-    {
-        for (int r = 3; r < 18 && !apply_rows; r += 3) {
-            int total = edge_wg;
-            for (int64_t b : lp.owned_blocks) total += apply_block_nwg(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), r);
-            if (total <= 512) apply_rows = r;
-        }
-    }
+    auto launch_wgs = [&](int rows, bool overlap) {   // workgroups of one interior + perimeter launch with chunks of `rows` (0 = the per-block rule)
+        int total = edge_wg;
+        for (int64_t b : lp.owned_blocks)
+            total += overlap ? apply_block_nwg_overlap(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), rows)
+                             : apply_block_nwg(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), rows);
+        return total;
+    };
+    auto shortest_rows = [&](bool overlap) {
+        for (int r = 3; r < 18; r += 3)
+            if (launch_wgs(r, overlap) <= 512) return r;
+        return 0;
+    };
+    apply_rows = shortest_rows(false);
+    // Layout of the two kernels of the two-kernel BiCGStab iteration (see vk_overlap below, where its tables are built): overlapping
+    // 62-column strips between 50 000 and 12 million nodes -- 128^2 .. 724^2 and 1200^2 .. 2896^2 -6 .. -12 % per iteration, the reference's examples
+    // T106 / LS89 26.6 -> 22.9 / 28.4 -> 24.0 us, the same meshes refined 2 .. 8 x (8 blocks, O-grid blocks of 81 columns) -22 .. -29 %
+    // (tools/dev/vk_overlap_sizes.py, o4h_refined_trace.py) -- with ONE exception, 1024^2 (72 -> 79 us): four 256-column workgroups per
+    // chunk row fit its 1024 columns exactly and their 228 workgroups find a CU each, the 62-column strips need five per chunk row and
+    // 285.  So: unless the launch with halo loads fits one workgroup per CU and the one with overlapping strips does not.
+    const bool vk_able = !has_hooks && opt.inner == TM_INNER_BICGSTAB && !(opt.flags & TM_OPT_EAGER_SCALARS);
+    // (from 50 000 nodes on: below, the layouts are 3-4 us of ~25 per iteration apart, and the reference's own examples -- 25 / 38 k nodes, whose
+    // late Picard iterates amplify every rounding difference a hundredfold, DESIGN.md section 2 -- keep the layout their parity figures were taken with)
+    vk_overlap = vk_able && lp.n_owned >= 50000 && lp.n_owned <= 12000000;
+    if (vk_overlap && launch_wgs(apply_rows, false) <= 256 && launch_wgs(shortest_rows(true), true) > 256) vk_overlap = false;
+    if (const char* e = std::getenv("TM_VK_OVERLAP")) vk_overlap = vk_able && std::atoi(e) != 0;   // forces it off / on (A/B runs, tests)
+    if (vk_overlap) apply_rows = shortest_rows(true);   // chunks for the layout that runs (never shorter than the other layout's, which has fewer workgroups per chunk row: both stay within the 512 partial rows of the lazy scalar steps)
     // a relax handle launches K2 for single sweeps only (one per pass: TM_OPT_SINGLE_SWEEP, the odd sweep behind pairs / triples): that
     // pass is bandwidth-bound and prefers chunks of ONE six-row load group -- 4096^2: 90.8 against 96.8 us with 18 rows (0.74 against
     // 0.69 of the HBM peak), 2048^2 28.1 / 28.6, 1024^2 8.1 / 8.6 (tools/dev/steady_time.py, STEADY_SINGLE=1); the Krylov kernels,
@@ -686,13 +705,10 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     const int nwg3_all = fuse_triples ? nwg_apply3 : (triples_coupled ? nwg_apply3 + std::max(edge_L[2].nwg, fused_levels.nstrips) : 0);
     // Overlapping strips for the two kernels of the two-kernel BiCGStab iteration (single process, no preconditioner -- where fuse2 holds,
     // below): no halo registers -> 234 instead of 276 VGPRs for VK_R, two workgroups per CU without spills.  Where it pays was MEASURED, same
-    // box, alternating runs (tools/dev/vk_overlap_sizes.py, us per iteration halo loads / overlapping strips): 1024^2 74.4 / 80.0,
-    // 1448^2 124.7 / 110.7, 2048^2 271.2 / 255.7, 2896^2 516.0 / 485.9, 4096^2 862-882 / 870-918, 5792^2 1610 / 1733 -- i.e. between
-    // ~1.5 and ~12 million nodes per process, where the seven read and four write streams of the pass still find part of their rows in the
-    // Infinity Cache; at 4096^2 and beyond the pass is bound by the HBM streams alone and the 3 % of re-read columns cost what the
-    // second workgroup per CU gives.  TM_VK_OVERLAP=0/1 forces it off / on (A/B runs, the tests on small meshes).
-    vk_overlap = !has_hooks && opt.inner == TM_INNER_BICGSTAB && !(opt.flags & TM_OPT_EAGER_SCALARS) && lp.n_owned >= 1500000 && lp.n_owned <= 12000000;
-    if (const char* e = std::getenv("TM_VK_OVERLAP")) vk_overlap = !has_hooks && opt.inner == TM_INNER_BICGSTAB && !(opt.flags & TM_OPT_EAGER_SCALARS) && std::atoi(e) != 0;
+    // box, alternating runs (tools/dev/vk_overlap_sizes.py, us per iteration halo loads / overlapping strips): 128^2 20.1 / 17.9, 512^2 34.3 / 31.8,
+    // 724^2 49.8 / 44.3, 1024^2 72-74 / 79-80, 1200^2 97.1 / 86.0, 1448^2 124.7 / 110.7, 2048^2 271.2 / 255.7, 2896^2 516.0 / 485.9,
+    // 4096^2 862-882 / 870-918, 5792^2 1610 / 1733: at 4096^2 and beyond the pass is bound by the HBM streams alone and the 3 % of re-read
+    // columns cost what the second workgroup per CU gives.  The decision is taken with the chunk heights above.
     if (vk_overlap) {
         int off_ov = 0;
         for (int64_t b : lp.owned_blocks) {
