@@ -718,10 +718,15 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         poff_edge_ov = off_ov;
         nwg_apply_ov = off_ov + edge.nwg;
     }
-    const uint64_t npart = static_cast<uint64_t>(std::max(std::max(std::max(std::max(nwg_apply, nwg_apply_ov), nwg_apply2), nwg3_all), nwg_vec)) * MAX_PARTIALS;
     // Krylov modes on a small single-process mesh: the scalar steps travel with the kernels that consume their result (LazyScalars,
     // tm_kernels.h) -- three partial-sum buffers in rotation, two scalar blocks
+    // (the two-kernel BiCGStab iteration launches no vector kernel inside its loop: there the interior + perimeter launches alone decide
+    // whether the scalar steps can travel lazily, and the few vector kernels around the loop take 512 workgroups -- T106 / LS89 refined 4 x,
+    // 0.28 / 0.41 M nodes: 46.2 -> 42.8 / 62.6 -> 59.4 us per iteration, same iterates bit for bit; more than 512 partial rows do NOT pay:
+    // 2048 of them in every workgroup's prologue made T106 x 8 115 instead of 95 us)
+    if (vk_able && std::max(nwg_apply, nwg_apply_ov) <= 512) nwg_vec = std::min(nwg_vec, 512);
     lazy = !has_hooks && opt.inner != TM_INNER_RELAX && std::max(std::max(nwg_apply, nwg_apply_ov), nwg_vec) <= 512 && !(opt.flags & TM_OPT_EAGER_SCALARS);
+    const uint64_t npart = static_cast<uint64_t>(std::max(std::max(std::max(std::max(nwg_apply, nwg_apply_ov), nwg_apply2), nwg3_all), nwg_vec)) * MAX_PARTIALS;
     // second apply of an iteration with the s-update folded in: single process (nothing of s has to travel) and no preconditioner
     // (which wants s as a stored vector)
     fuse_s = !has_hooks && opt.inner == TM_INNER_BICGSTAB && !(opt.flags & TM_OPT_EAGER_SCALARS);
