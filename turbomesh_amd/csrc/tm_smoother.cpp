@@ -615,8 +615,12 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
                              : apply_block_nwg(static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), rows);
         return total;
     };
+    // (the two-kernel BiCGStab iteration looks further, up to 36 rows: staying within 512 workgroups keeps its scalar steps lazy, which is worth
+    // more than short chunks once the launch fills the device anyway -- single blocks 1500^2 / 1700^2 / 1900^2: 139 -> 121, 163 -> 144,
+    // 198 -> 189 us per iteration, T106 refined 8 x 95 -> 90.5; every other path keeps the rule it was tuned with)
+    const bool vk_able = !has_hooks && opt.inner == TM_INNER_BICGSTAB && !(opt.flags & TM_OPT_EAGER_SCALARS);
     auto shortest_rows = [&](bool overlap) {
-        for (int r = 3; r < 18; r += 3)
+        for (int r = 3; r <= (vk_able ? 36 : 15); r += 3)
             if (launch_wgs(r, overlap) <= 512) return r;
         return 0;
     };
@@ -627,7 +631,6 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     // (tools/dev/vk_overlap_sizes.py, o4h_refined_trace.py) -- with ONE exception, 1024^2 (72 -> 79 us): four 256-column workgroups per
     // chunk row fit its 1024 columns exactly and their 228 workgroups find a CU each, the 62-column strips need five per chunk row and
     // 285.  So: unless the launch with halo loads fits one workgroup per CU and the one with overlapping strips does not.
-    const bool vk_able = !has_hooks && opt.inner == TM_INNER_BICGSTAB && !(opt.flags & TM_OPT_EAGER_SCALARS);
     // (from 50 000 nodes on: below, the layouts are 3-4 us of ~25 per iteration apart, and the reference's own examples -- 25 / 38 k nodes, whose
     // late Picard iterates amplify every rounding difference a hundredfold, DESIGN.md section 2 -- keep the layout their parity figures were taken with)
     vk_overlap = vk_able && lp.n_owned >= 50000 && lp.n_owned <= 12000000;
