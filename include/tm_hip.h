@@ -128,7 +128,9 @@ enum {
                                 TM_INNER_MG_BICGSTAB when the largest block has >= 100 000 nodes, TM_INNER_BICGSTAB below -- on the
                                 reference's example meshes (T106 / LS89: 8 blocks of 10^2..10^4 nodes) every multigrid level is a handful
                                 of launch-bound kernels and the plain solver is 7x faster in wall time; from ~300^2 nodes per block on
-                                the cycle's O(1) iteration count wins.  A single-process handle (no rank hooks)
+                                the cycle's O(1) iteration count wins; blocks that no connection couples take
+                                the cycle from 1000 nodes on (it is block-local: a lone block needs ~25 iterations at any size, coupled
+                                blocks hundreds).  A single-process handle (no rank hooks)
                                 also looks at the coordinates it is given: where the cells' aspect ratio varies strongly INSIDE a block
                                 (standard deviation of log(|x_xi|^2 / |x_eta|^2) over the block's nodes above 1: boundary-layer
                                 clustering) the point-Jacobi cycle is a poor preconditioner and the plain solve is chosen at any size.

@@ -6,7 +6,7 @@ The example inputs name the reference's own solvers ("gmres" + "ilu0"), which st
 without UMFPACK answers error.ExternalSolverNotEnabled, this program refuses them -- unless --hip replaces the solver entry
 by {"hip": {"inner": "auto"}} (what a user would write into the JSON): the plain Picard + BiCGStab solve on meshes of small blocks
 like the reference's examples (T106 / LS89: 7x faster there than the multigrid-preconditioned one), the multigrid-preconditioned
-solve once a block has 100 000 nodes or more and the cells' aspect ratio does not vary strongly inside any block (refined O-grids with
+solve once a block has 100 000 nodes or more (1000 when the blocks are not coupled) and the cells' aspect ratio does not vary strongly inside any block (refined O-grids with
 boundary-layer clustering keep the plain solve)."""
 from __future__ import annotations
 

@@ -159,7 +159,12 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
         uint64_t largest = 0;
         if (mesh && mesh->blocks)
             for (uint64_t b = 0; b < mesh->nblocks; ++b) largest = std::max<uint64_t>(largest, mesh->blocks[b].ni * mesh->blocks[b].nj);
-        bool cycle = largest >= AUTO_MG_MIN_BLOCK_NODES;
+        // (blocks that no connection couples are the cycle's home ground at ANY size -- a lone 33^2 block 5.0 against 7.3 ms per three Picard
+        // iterations, 200^2 11 against 37, 1024^2 13 against 666 -- whereas across interfaces the block-local cycle leaves the coupling to the
+        // Krylov iteration and needs 200-1400 iterations where a lone block needs 25: 8 coupled 256^2 blocks 978 against 323 ms, and only
+        // from ~512^2 per block on does it win again, 8 x 512^2 1.6 against 2.1 s, 2 x 2048^2 1.8 against 24.8 s: tools/dev/auto_crossover.py)
+        const bool uncoupled = mesh && mesh->nconns == 0;
+        bool cycle = largest >= (uncoupled ? AUTO_MG_MIN_LONE_BLOCK_NODES : AUTO_MG_MIN_BLOCK_NODES);
         // ... and cells whose aspect ratio does not vary much inside a block.  Read off the caller's coordinates, which only a single-process
         // handle is sure to have for every block (the ranks of a job must decide alike, so with hooks the sizes decide alone; so does
         // the sizing call, whose answer has to cover whatever create decides later)

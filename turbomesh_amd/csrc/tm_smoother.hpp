@@ -265,6 +265,7 @@ int rccl_hooks_allow_triples(const tm_comm_hooks* h);
 
 // TM_INNER_AUTO: the multigrid-preconditioned solve from this many nodes in the largest block on (include/tm_hip.h)
 constexpr uint64_t AUTO_MG_MIN_BLOCK_NODES = 100000;
+constexpr uint64_t AUTO_MG_MIN_LONE_BLOCK_NODES = 1000;   // ... and from this many when no connection couples the blocks (tm_smoother.cpp)
 // ... unless the cells' aspect ratio VARIES inside a block (standard deviation of log(g11/g22) over the block's nodes above this): the cycle
 // smooths with point Jacobi and coarsens a block by one rule, so boundary-layer clustering (the reference's O-grids: 1.4-1.8; the
 // uniform synthetic blocks: 0.3) leaves it a poor preconditioner -- T106 / LS89 refined to 0.9 / 1.3 M nodes: 14.5 / 21 s against

@@ -34,7 +34,7 @@ class Inner(enum.IntEnum):
     relax = _capi.TM_INNER_RELAX         # one fused Jacobi elliptic sweep per outer iteration
     mg_bicgstab = _capi.TM_INNER_MG_BICGSTAB   # bicgstab, right-preconditioned by one multigrid V-cycle per block
     gmres = _capi.TM_INNER_GMRES         # Picard + restarted GMRES(30), diagonal left preconditioner (GMRES.zig:300-423 on the device)
-    auto = _capi.TM_INNER_AUTO           # mg_bicgstab when the largest block has >= 100 000 nodes and no block's cell aspect ratio varies strongly (boundary-layer clustering), bicgstab otherwise (decided at create)
+    auto = _capi.TM_INNER_AUTO           # mg_bicgstab when the largest block has >= 100 000 nodes (>= 1000 when no connection couples the blocks) and no block's cell aspect ratio varies strongly (boundary-layer clustering), bicgstab otherwise (decided at create)
 
 
 @dataclass
