@@ -221,3 +221,44 @@ def test_two_per_pass_with_a_control_function_and_many_blocks(monkeypatch):
             out.append((mesh_flat(mesh), st["inner_iterations"]))
         assert out[0][1] == out[1][1]
         assert np.array_equal(out[0][0], out[1][0])
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("name", ["strip3_reversed", "two_by_two_junction", "channel_periodic_sliding", "strip2_40x300"])
+def test_perimeter_step_of_the_preconditioner_changes_the_route_only(name, monkeypatch):
+    # round 4 (late): across interfaces the block-local cycle used to leave the perimeter unknowns with their diagonal; now the perimeter rows are
+    # applied to the interior corrections behind the cycles (e_p = f_p - (D^-1 A)_pI e_I, Smoother::precondition).  A preconditioner changes
+    # the route, not the destination: same Picard iterates as without the step and as the exact-solve oracle, in fewer inner iterations.
+    out = {}
+    for step in ("0", "1"):
+        monkeypatch.setenv("TM_MG_PERIMETER_STEP", step)
+        mesh = TOPOLOGIES[name]()
+        with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab)) as sm:
+            st = sm.iterate(3)
+            sm.download()
+        assert st["not_converged"] == 0
+        out[step] = (mesh_flat(mesh), st["inner_iterations"])
+    om = OracleMesh(TOPOLOGIES[name]())
+    oracle.picard_exact(om, 3)
+    rms = _rms(out["0"][0], out["1"][0])
+    print(f"[perimeter step] {name}: inner iterations {out['0'][1]} -> {out['1'][1]}, iterates {rms:.1e} apart, {_rms(out['1'][0], om.flat()):.1e} from the exact ones")
+    assert rms <= 1e-10 and _rms(out["1"][0], om.flat()) <= 1e-10
+    assert out["1"][1] <= out["0"][1]
+
+
+@pytest.mark.gpu
+def test_perimeter_step_cuts_the_iterations_on_a_coupled_strip(monkeypatch):
+    counts = {}
+    for step in ("0", "1"):
+        monkeypatch.setenv("TM_MG_PERIMETER_STEP", step)
+        mesh = configs.strip(4, 96, 128)
+        rng = np.random.default_rng(5)
+        for b in mesh.blocks:
+            d = b.points.data
+            d[1:-1, 1:-1] += 0.25 / d.shape[0] * (rng.random(d[1:-1, 1:-1].shape) - 0.5)
+        with smooth.Smoother(mesh, solver.Option.hip(inner=solver.Inner.mg_bicgstab)) as sm:
+            st = sm.iterate(2)
+        assert st["not_converged"] == 0
+        counts[step] = st["inner_iterations"]
+    print(f"[perimeter step] strip 4 x 96 x 128: inner iterations {counts['0']} -> {counts['1']}")
+    assert counts["1"] <= 0.85 * counts["0"], counts

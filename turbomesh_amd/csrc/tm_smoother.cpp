@@ -243,6 +243,10 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     X = vec();
     U = vec();
     use_mg = opt.inner == TM_INNER_MG_BICGSTAB;
+    // the perimeter step of the preconditioner (precondition()): single process (across ranks it would take an exchange of the corrections inside
+    // every application), meshes with connections (all-fixed perimeters have identity rows: nothing to apply)
+    mg_perimeter_step = use_mg && !has_hooks && (!topo.conns.empty() || !topo.bcs.empty());
+    if (const char* e = std::getenv("TM_MG_PERIMETER_STEP")) mg_perimeter_step = mg_perimeter_step && std::atoi(e) != 0;
     if (opt.inner == TM_INNER_GMRES) {   // w / z of GMRES.zig:27-38 in one vector, the basis v_0 .. v_m contiguous behind it
         r = vec();
         gm_V = arena.alloc_n<double2>(static_cast<uint64_t>(n_local) * (GMRES_M + 1));
@@ -1123,8 +1127,19 @@ void Smoother::precondition(const double2* in, double2* out) {
     for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
         const int64_t b = lp.owned_blocks[k];
         const int64_t ls = lp.local_start[k];
-        mg[k].vcycle(in + ls, out + ls, mg_w0 + ls, mg_w1 + ls, stream);
-        HIPCHK(launch_copy_perimeter(in + ls, out + ls, static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), stream));
+        mg[k].vcycle(in + ls, out + ls, mg_w0 + ls, mg_w1 + ls, stream);   // (leaves the perimeter of out zero)
+        if (!mg_perimeter_step) HIPCHK(launch_copy_perimeter(in + ls, out + ls, static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), stream));
+    }
+    if (!mg_perimeter_step) return;
+    // Coupled blocks: the perimeter unknowns are not left with their diagonal alone -- e_p = f_p - (D^-1 A)_pI e_I, the perimeter rows applied to
+    // the interior corrections just computed (block upper-triangular instead of block-diagonal: the rows of an interface see the
+    // corrections of the first interior rows either side of it).  One perimeter-row launch and a subtraction per block; `t` is free
+    // whenever a preconditioner application runs (picard_bicgstab) and lends its perimeter entries.
+    HIPCHK(launch_edge_rows(edge, out, X, PQ, nullptr, t, 0.0, MODE_SCALED, DOT_NONE, nullptr, stream));
+    for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
+        const int64_t b = lp.owned_blocks[k];
+        const int64_t ls = lp.local_start[k];
+        HIPCHK(launch_perimeter_sub(in + ls, t + ls, out + ls, static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), stream));
     }
 }
 

@@ -68,6 +68,7 @@ struct Smoother {
     double2 *p_hat = nullptr, *s_hat = nullptr, *mg_w0 = nullptr, *mg_w1 = nullptr;
     std::vector<BlockMG> mg;
     bool use_mg = false;
+    bool mg_perimeter_step = false;   // the preconditioner applies the perimeter rows to the interior corrections (precondition())
     void precondition(const double2* in, double2* out);
     double2* M = nullptr;           // X^(k+1) of a fused pair of relax sweeps (perimeter + first-interior ring only)
     double2* M2 = nullptr;          // coupled triples: X^(k+2) on the perimeter and in the zone next to sides whose perimeter rows move
