@@ -243,9 +243,10 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     X = vec();
     U = vec();
     use_mg = opt.inner == TM_INNER_MG_BICGSTAB;
-    // the perimeter step of the preconditioner (precondition()): single process (across ranks it would take an exchange of the corrections inside
-    // every application), meshes with connections (all-fixed perimeters have identity rows: nothing to apply)
-    mg_perimeter_step = use_mg && !has_hooks && (!topo.conns.empty() || !topo.bcs.empty());
+    // the perimeter step of the preconditioner (precondition()): meshes with connections or sliding rows (all-fixed perimeters have identity rows:
+    // nothing to apply); decided by the global topology, so every rank of a job decides alike (across ranks the step takes an exchange of the
+    // corrections inside every application -- microseconds beside two cycles)
+    mg_perimeter_step = use_mg && (!topo.conns.empty() || !topo.bcs.empty());
     if (const char* e = std::getenv("TM_MG_PERIMETER_STEP")) mg_perimeter_step = mg_perimeter_step && std::atoi(e) != 0;
     if (opt.inner == TM_INNER_GMRES) {   // w / z of GMRES.zig:27-38 in one vector, the basis v_0 .. v_m contiguous behind it
         r = vec();
@@ -1135,6 +1136,10 @@ void Smoother::precondition(const double2* in, double2* out) {
     // the interior corrections just computed (block upper-triangular instead of block-diagonal: the rows of an interface see the
     // corrections of the first interior rows either side of it).  One perimeter-row launch and a subtraction per block; `t` is free
     // whenever a preconditioner application runs (picard_bicgstab) and lends its perimeter entries.
+    if (has_hooks) {   // the rows of an interface read the corrections of the neighbour's first interior rows: one more exchange per application
+        exchange(out);
+        exchange_finish();
+    }
     HIPCHK(launch_edge_rows(edge, out, X, PQ, nullptr, t, 0.0, MODE_SCALED, DOT_NONE, nullptr, stream));
     for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
         const int64_t b = lp.owned_blocks[k];
