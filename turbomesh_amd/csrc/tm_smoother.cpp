@@ -647,6 +647,10 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     if (vk_overlap && launch_wgs(apply_rows, false) <= 256 && launch_wgs(shortest_rows(true), true) > 256) vk_overlap = false;
     if (const char* e = std::getenv("TM_VK_OVERLAP")) vk_overlap = vk_able && std::atoi(e) != 0;   // forces it off / on (A/B runs, tests)
     if (vk_overlap) apply_rows = shortest_rows(true);   // chunks for the layout that runs (never shorter than the other layout's, which has fewer workgroups per chunk row: both stay within the 512 partial rows of the lazy scalar steps)
+    // ... and when no height fits: ONE height for all blocks of a multi-block mesh instead of the per-block rule, which hands blocks of 10^4 nodes
+    // 3-row chunks (5 rows read per 3) beside 18-row chunks of the large ones -- LS89 refined 8 x 124.5 -> 110.2, T106 12 x 153.0 -> 130.7,
+    // LS89 12 x 206.6 -> 204.9 us per iteration with 24 rows (18: 124.0 / 150.2 / 185.1; 36: 130.2 / 142.4 / 193.0)
+    if (vk_able && !apply_rows && lp.owned_blocks.size() > 1) apply_rows = 24;
     // a relax handle launches K2 for single sweeps only (one per pass: TM_OPT_SINGLE_SWEEP, the odd sweep behind pairs / triples): that
     // pass is bandwidth-bound and prefers chunks of ONE six-row load group -- 4096^2: 90.8 against 96.8 us with 18 rows (0.74 against
     // 0.69 of the HBM peak), 2048^2 28.1 / 28.6, 1024^2 8.1 / 8.6 (tools/dev/steady_time.py, STEADY_SINGLE=1); the Krylov kernels,
