@@ -18,7 +18,7 @@ if len(sys.argv) <= 1 or os.environ.get("CROSSOVER_STRIPS"):
     cases += [(f"strip {k} x {ni} x {nj}", (lambda k=k, ni=ni, nj=nj: strip(k, ni, nj))) for k, ni, nj in ([tuple(int(x) for x in t.split('x')) for t in os.environ['CROSSOVER_STRIPS'].split(',')] if 'x' in os.environ.get('CROSSOVER_STRIPS', '') else ((4, 64, 256), (8, 64, 64), (8, 128, 128), (2, 200, 200), (8, 256, 256)))]
 for name, build in cases:
     row = []
-    for inner in (solver.Inner.bicgstab, solver.Inner.mg_bicgstab):
+    for inner in ((solver.Inner.mg_bicgstab, solver.Inner.mg_bicgstab) if os.environ.get("CROSSOVER_MG_ONLY") else (solver.Inner.bicgstab, solver.Inner.mg_bicgstab)):
         best = None
         for rep in range(2):
             mesh = build()
