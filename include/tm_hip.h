@@ -117,7 +117,7 @@ enum {
     TM_INNER_RELAX = 1,      /* every outer iteration is ONE fused Jacobi elliptic sweep X <- X + omega D^-1 (b - A(X) X)   */
     TM_INNER_MG_BICGSTAB = 2,/* TM_INNER_BICGSTAB, right-preconditioned by one geometric-multigrid V(2,2) cycle per block
                                 (damped Jacobi, full weighting, rediscretised Winslow operator on vertex-coarsened levels;
-                                perimeter rows keep the identity).  Same Picard iterates, far fewer inner iterations on
+                                the perimeter rows are applied to the interior corrections behind the cycles).  Same Picard iterates, far fewer inner iterations on
                                 large blocks: what makes "to 1e-8 residual at 4096^2" practical               */
     TM_INNER_GMRES = 4,      /* the Picard outer iteration with the reference's OTHER Krylov solver restated on the device: restarted GMRES(30),
                                 left-preconditioned with the diagonal, modified Gram-Schmidt Arnoldi, Givens rotations (GMRES.zig:300-423,

@@ -162,7 +162,8 @@ def test_multi_rank_equals_single_rank(name, builder, owner):
 
 
 def test_multi_rank_multigrid_preconditioner():
-    # the V-cycle is block-local (no communication); the outer BiCGStab's exchanges / all-reduces are the same as without it
+    # the V-cycle is block-local (no communication); the perimeter step behind the cycles takes one exchange of the corrections per application,
+    # the outer BiCGStab's exchanges / all-reduces are the same as without a preconditioner
     from turbomesh_amd.smoothing import smooth
 
     builder = lambda: configs.strip(3, 70, 150, reverse_odd=True)
