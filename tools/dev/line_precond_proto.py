@@ -3,7 +3,7 @@
 row-equilibrated operator with the diagonal alone, with line relaxation along j, along i, alternating (j then i, one residual in
 between), and with ILU(0) -- before anyone writes batched tridiagonal solves for the GPU.  Result (round 4): T106 442 / 319 / 348 / 144 /
 788, LS89 658 / 579 / 718 / 456 / 1043 -- the alternating sweep costs two line solves and an operator application per use and so does not
-pay, the single directions gain a quarter at best.  usage: line_precond_proto.py [T106|LS89]"""
+pay, the single directions gain a quarter at best.  usage: line_precond_proto.py [T106|LS89] [refinement factor = 1]"""
 import sys, time, numpy as np, scipy.sparse as sp, scipy.sparse.linalg as spla
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__)))))
 from oracle import oracle
@@ -11,7 +11,19 @@ from tests.conftest import OracleMesh, oracle_tfi
 import bench
 name = sys.argv[1] if len(sys.argv)>1 else 'T106'
 from tests.test_o4h import load
-_, mesh = load(name, oracle_tfi)
+factor = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+if factor == 1:
+    _, mesh = load(name, oracle_tfi)
+else:   # the example refined like tools/dev/o4h_auto_probe.py does
+    import json, os
+    from turbomesh_amd.input import Input
+    GOLD = os.path.join(os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))), "tests", "golden")
+    j = json.load(open(os.path.join(GOLD, "examples", name, name + ".json")))
+    nc = j["template"]["O4H"]["num_cells"]
+    for k in nc:
+        nc[k] *= min(factor, 2) if k == "o_grid" else factor
+    inp = Input.parse(json.dumps(j))
+    mesh = inp.template.run(inp.geometry(GOLD), tfi=oracle_tfi)
 om = OracleMesh(mesh)
 s = oracle.System(om); s.fill(0); s.fill_x_specific()
 A = s.csr().tocsr(); b = s.rhs_x.copy(); n = A.shape[0]
@@ -35,7 +47,7 @@ def line_factor(direction):
     else: keep=same&(jr==jc)&(np.abs(ir-ic)<=1)
     T=sp.csr_matrix((Bc.data[keep],(Bc.row[keep],Bc.col[keep])),shape=(n,n))
     return spla.splu(T.tocsc())
-def bicgstab(apply_prec, rtol=1e-10, maxit=5000):
+def bicgstab(apply_prec, rtol=1e-10, maxit=40000):
     x=x0.copy(); r=bs-B@x; rh=r.copy(); rho=alpha=om_=1.0; v=np.zeros(n); p=np.zeros(n)
     tol=rtol*np.linalg.norm(bs)
     for it in range(1,maxit+1):
