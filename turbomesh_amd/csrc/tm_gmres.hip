@@ -269,4 +269,70 @@ hipError_t launch_perimeter_sub(const double2* in, const double2* h, double2* ou
     return hipGetLastError();
 }
 
+// ------------------------------------------------------------------------------------------
+// The other half of the preconditioner's perimeter treatment: the perimeter values f_p as DIRICHLET DATA of the block's cycle, i.e. the
+// right-hand side of the first interior ring becomes f_I - (D^-1 A)_Ip f_p for the duration of the cycle (saved, changed, restored to the bit
+// by k_ring_restore -- the vector is the Krylov method's own p or s).  A thread per ring node: the row's nine coefficients as
+// stencil_coefs forms them (tm_kernels.hip; smooth.zig:171-216), the sum over the neighbours that lie on the perimeter, scaled by
+// the diagonal like MODE_SCALED.  Any fixed linear operator would do here: this shapes the preconditioner, not the system.
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ bool ring_node(int k, int ni, int nj, int& i, int& j) {   // 2 (nj - 2) + 2 (ni - 4) nodes, ni, nj >= 5
+    const int w = nj - 2;
+    if (k < w) { i = 1; j = 1 + k; return true; }
+    if (k < 2 * w) { i = ni - 2; j = 1 + (k - w); return true; }
+    const int q = k - 2 * w;
+    i = 2 + (q >> 1);
+    j = (q & 1) ? nj - 2 : 1;
+    return i <= ni - 3;
+}
+template <bool HAS_PQ>
+__global__ __launch_bounds__(256) void k_ring_dirichlet(double2* __restrict__ f, const double2* __restrict__ X, const double2* __restrict__ PQ, double2* __restrict__ save,
+                                                        int ni, int nj) {
+    int i, j;
+    if (!ring_node(blockIdx.x * 256 + threadIdx.x, ni, nj, i, j)) return;
+    const size_t id = static_cast<size_t>(i) * nj + j;
+    const double2 xm = X[id - nj], xp = X[id + nj], xl = X[id - 1], xr = X[id + 1];
+    const double x_xi = 0.5 * (xp.x - xm.x), y_xi = 0.5 * (xp.y - xm.y), x_eta = 0.5 * (xr.x - xl.x), y_eta = 0.5 * (xr.y - xl.y);
+    const double g22 = x_eta * x_eta + y_eta * y_eta, g12 = x_xi * x_eta + y_xi * y_eta, g11 = x_xi * x_xi + y_xi * y_xi;
+    const double diag = -2.0 * g22 - 2.0 * g11;
+    double P = 0.0, Q = 0.0;
+    if (HAS_PQ) { const double2 pq = PQ[id]; P = pq.x; Q = pq.y; }
+    const double c_ip = g22 * (1.0 + 0.5 * P), c_im = g22 * (1.0 - 0.5 * P), c_jp = g11 * (1.0 + 0.5 * Q), c_jm = g11 * (1.0 - 0.5 * Q);
+    const double c_pp = -0.5 * g12, c_pm = 0.5 * g12, c_mp = 0.5 * g12, c_mm = -0.5 * g12;
+    const bool top = i == 1, bottom = i == ni - 2, left = j == 1, right = j == nj - 2;   // the neighbours beyond are perimeter nodes
+    double sx = 0.0, sy = 0.0;
+    auto add = [&](double c, size_t at) { const double2 v = f[at]; sx += c * v.x; sy += c * v.y; };
+    if (top) add(c_im, id - nj);
+    if (bottom) add(c_ip, id + nj);
+    if (left) add(c_jm, id - 1);
+    if (right) add(c_jp, id + 1);
+    if (top || left) add(c_mm, id - nj - 1);
+    if (top || right) add(c_mp, id - nj + 1);
+    if (bottom || left) add(c_pm, id + nj - 1);
+    if (bottom || right) add(c_pp, id + nj + 1);
+    const double dinv = (diag == 0.0) ? 1.0 : 1.0 / diag;
+    const double2 v = f[id];
+    save[id] = v;
+    f[id] = make_double2(v.x - sx * dinv, v.y - sy * dinv);
+}
+__global__ __launch_bounds__(256) void k_ring_restore(double2* __restrict__ f, const double2* __restrict__ save, int ni, int nj) {
+    int i, j;
+    if (!ring_node(blockIdx.x * 256 + threadIdx.x, ni, nj, i, j)) return;
+    const size_t id = static_cast<size_t>(i) * nj + j;
+    f[id] = save[id];
+}
+hipError_t launch_ring_dirichlet(double2* f, const double2* X, const double2* PQ, double2* save, int ni, int nj, hipStream_t st) {
+    if (ni < 5 || nj < 5) return hipSuccess;
+    const int n = 2 * (nj - 2) + 2 * (ni - 4);
+    if (PQ) hipLaunchKernelGGL(k_ring_dirichlet<true>, dim3((n + 255) / 256), dim3(256), 0, st, f, X, PQ, save, ni, nj);
+    else hipLaunchKernelGGL(k_ring_dirichlet<false>, dim3((n + 255) / 256), dim3(256), 0, st, f, X, PQ, save, ni, nj);
+    return hipGetLastError();
+}
+hipError_t launch_ring_restore(double2* f, const double2* save, int ni, int nj, hipStream_t st) {
+    if (ni < 5 || nj < 5) return hipSuccess;
+    const int n = 2 * (nj - 2) + 2 * (ni - 4);
+    hipLaunchKernelGGL(k_ring_restore, dim3((n + 255) / 256), dim3(256), 0, st, f, save, ni, nj);
+    return hipGetLastError();
+}
+
 }  // namespace tmh

@@ -1,8 +1,9 @@
 // Block-local geometric multigrid for the frozen-coefficient error equation (SURVEY "next" N4): the preconditioner of
 // TM_INNER_MG_BICGSTAB.  One V-cycle approximates e = (D^-1 A_II)^-1 f on the interior rows of ONE block with e = 0 on
 // its perimeter; the coupling between blocks is left to the outer Krylov iteration, so the cycle itself needs no communication.
-// (The perimeter unknowns are not left with their diagonal alone: behind the cycles of all blocks the caller applies the perimeter
-// rows to the interior corrections, e_p = f_p - (D^-1 A)_pI e_I -- Smoother::precondition.)
+// (The perimeter unknowns are not left with their diagonal alone: the caller hands their values to the cycle as Dirichlet data -- the
+// right-hand side of the first interior ring is f_I - (D^-1 A)_Ip f_p while the cycle runs -- and applies the perimeter rows to the interior
+// corrections behind the cycles of all blocks, e_p = f_p - (D^-1 A)_pI e_I: Smoother::precondition.)
 //   levels      vertex coarsening per direction while it has >= 5 nodes: coarse node c sits on fine node min(2c, n-1)
 //               (4096 -> 2049 -> 1025 -> ... -> 3: one short last cell whenever n is even).  Point Jacobi only smooths along
 //               strong couplings, so while the block's mean cell aspect ratio g11/g22 = |x_xi|^2/|x_eta|^2 is off by more than

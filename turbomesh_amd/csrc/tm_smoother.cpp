@@ -248,6 +248,8 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     // corrections inside every application -- microseconds beside two cycles)
     mg_perimeter_step = use_mg && (!topo.conns.empty() || !topo.bcs.empty());
     if (const char* e = std::getenv("TM_MG_PERIMETER_STEP")) mg_perimeter_step = mg_perimeter_step && std::atoi(e) != 0;
+    mg_dirichlet = mg_perimeter_step;   // ... and the perimeter values as Dirichlet data in front of the cycles (block-local: no exchange)
+    if (const char* e = std::getenv("TM_MG_DIRICHLET")) mg_dirichlet = mg_dirichlet && std::atoi(e) != 0;
     if (opt.inner == TM_INNER_GMRES) {   // w / z of GMRES.zig:27-38 in one vector, the basis v_0 .. v_m contiguous behind it
         r = vec();
         gm_V = arena.alloc_n<double2>(static_cast<uint64_t>(n_local) * (GMRES_M + 1));
@@ -1129,11 +1131,16 @@ void Smoother::white_launch(int update) {
 
 // out = M^-1 in: one V-cycle per owned block on the interior rows, identity on the perimeter rows (tm_multigrid.hpp)
 void Smoother::precondition(const double2* in, double2* out) {
+    double2* const in_w = const_cast<double2*>(in);   // (its first interior ring is changed for the duration of the cycles and restored to the bit)
     for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
         const int64_t b = lp.owned_blocks[k];
         const int64_t ls = lp.local_start[k];
+        const int bi = static_cast<int>(topo.ni[b]), bj = static_cast<int>(topo.nj[b]);
+        // the perimeter values as Dirichlet data of the block's cycle: f_I - (D^-1 A)_Ip f_p on the first interior ring (originals parked in t)
+        if (mg_dirichlet) HIPCHK(launch_ring_dirichlet(in_w + ls, X + ls, PQ ? PQ + ls : nullptr, t + ls, bi, bj, stream));
         mg[k].vcycle(in + ls, out + ls, mg_w0 + ls, mg_w1 + ls, stream);   // (leaves the perimeter of out zero)
-        if (!mg_perimeter_step) HIPCHK(launch_copy_perimeter(in + ls, out + ls, static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), stream));
+        if (mg_dirichlet) HIPCHK(launch_ring_restore(in_w + ls, t + ls, bi, bj, stream));
+        if (!mg_perimeter_step) HIPCHK(launch_copy_perimeter(in + ls, out + ls, bi, bj, stream));
     }
     if (!mg_perimeter_step) return;
     // Coupled blocks: the perimeter unknowns are not left with their diagonal alone -- e_p = f_p - (D^-1 A)_pI e_I, the perimeter rows applied to

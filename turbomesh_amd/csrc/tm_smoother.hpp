@@ -69,6 +69,7 @@ struct Smoother {
     std::vector<BlockMG> mg;
     bool use_mg = false;
     bool mg_perimeter_step = false;   // the preconditioner applies the perimeter rows to the interior corrections (precondition())
+    bool mg_dirichlet = false;   // ... and hands the perimeter values to the cycles as Dirichlet data (precondition())
     void precondition(const double2* in, double2* out);
     double2* M = nullptr;           // X^(k+1) of a fused pair of relax sweeps (perimeter + first-interior ring only)
     double2* M2 = nullptr;          // coupled triples: X^(k+2) on the perimeter and in the zone next to sides whose perimeter rows move
