@@ -43,6 +43,18 @@ def upper(f):
     e = jacobi(f); e[P] = f[P] - BPI @ e[I]; return e
 def symmetric(f):
     e = lower(f); e[P] = f[P] - BPI @ e[I]; return e
+BPP = spla.splu(B[P][:, P].tocsc())
+def symmetric_pp(f):   # the same with the perimeter-perimeter couplings (along the interface, connected copies) solved exactly instead of ignored
+    e = f.copy(); e[P] = BPP.solve(f[P]); e[I] = BII.solve(f[I] - BIP @ e[P]); e[P] = BPP.solve(f[P] - BPI @ e[I]); return e
+BPPo = (B[P][:, P] - sp.identity(len(P))).tocsr()   # off-diagonal part (unit diagonal: the rows are equilibrated)
+def jac(rhs, k):   # k Jacobi sweeps on B_PP e = rhs from e = rhs
+    e = rhs.copy()
+    for _ in range(k): e = rhs - BPPo @ e
+    return e
+def make_sym_jac(k1, k2):
+    def f_(f):
+        e = f.copy(); e[P] = jac(f[P], k1); e[I] = BII.solve(f[I] - BIP @ e[P]); e[P] = jac(f[P] - BPI @ e[I], k2); return e
+    return f_
 def bicgstab(prec, rtol=1e-10, maxit=20000):
     x = x0.copy(); r = bs - B @ x; rh = r.copy(); rho = alpha = om_ = 1.0; v = np.zeros(n); p = np.zeros(n)
     tol = rtol * np.linalg.norm(bs)
@@ -53,7 +65,7 @@ def bicgstab(prec, rtol=1e-10, maxit=20000):
         if np.linalg.norm(r) <= tol: return it
     return maxit
 print(f"{k} x {ni} x {nj}: n {n}, perimeter unknowns {len(P)}")
-for name, f in (("diagonal only", lambda v: v), ("jacobi", jacobi), ("lower", lower), ("upper", upper), ("symmetric", symmetric)):
+for name, f in (("diagonal only", lambda v: v), ("jacobi", jacobi), ("lower", lower), ("upper", upper), ("symmetric", symmetric), ("symmetric + B_PP", symmetric_pp), ("sym, Jacobi 0+1", make_sym_jac(0, 1)), ("sym, Jacobi 0+2", make_sym_jac(0, 2)), ("sym, Jacobi 0+4", make_sym_jac(0, 4)), ("sym, Jacobi 2+2", make_sym_jac(2, 2)), ("sym, Jacobi 4+4", make_sym_jac(4, 4))):
     print(f"  {name:14s} {bicgstab(f):6d} iterations", flush=True)
 if os.environ.get("PROTO_CHECK"):
     # one application of each preconditioner as a stationary correction: how much of the residual does it remove?

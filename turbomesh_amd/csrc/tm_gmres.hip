@@ -246,8 +246,8 @@ hipError_t launch_gm_backsub(GmresScalars* G, hipStream_t st) {
 }
 
 // ------------------------------------------------------------------------------------------
-// The multigrid preconditioner's perimeter step (Smoother::precondition): out = in - h on the perimeter nodes of a block, nothing else
-// touched.  (Here, not beside k_copy_perimeter whose indexing it shares: profiles/traffic.json is keyed to the text of tm_kernels.hip.)
+// The multigrid preconditioner's perimeter step (Smoother::precondition): out = in - h + out on the perimeter nodes of a block, nothing else
+// touched -- with h = the perimeter rows applied to out, a Jacobi sweep on the (unit-diagonal) perimeter system; out = in - h when out was zero there.  (Here, not beside k_copy_perimeter whose indexing it shares: profiles/traffic.json is keyed to the text of tm_kernels.hip.)
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void k_perimeter_sub(const double2* __restrict__ in, const double2* __restrict__ h, double2* __restrict__ out, int ni, int nj) {
     const int k = blockIdx.x * 256 + threadIdx.x;   // 0..nj-1: row 0, nj..2nj-1: row ni-1, then columns 0 and nj-1 of rows 1..ni-2
@@ -260,8 +260,8 @@ __global__ __launch_bounds__(256) void k_perimeter_sub(const double2* __restrict
         if (i > ni - 2) return;
         id = static_cast<size_t>(i) * nj + ((q & 1) ? nj - 1 : 0);
     }
-    const double2 a = in[id], b = h[id];
-    out[id] = make_double2(a.x - b.x, a.y - b.y);
+    const double2 a = in[id], b = h[id], c = out[id];   // (out is zero there in the first pass: x + 0 == x to the bit)
+    out[id] = make_double2((a.x - b.x) + c.x, (a.y - b.y) + c.y);
 }
 hipError_t launch_perimeter_sub(const double2* in, const double2* h, double2* out, int ni, int nj, hipStream_t st) {
     const int n = 2 * nj + 2 * (ni - 2);

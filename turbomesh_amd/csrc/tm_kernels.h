@@ -331,7 +331,7 @@ hipError_t launch_gather_rows(const double2* src, const int32_t* ids, int64_t n,
 
 // out perimeter <- in perimeter of one block (fixed boundary of the stand-alone relax sweep)
 hipError_t launch_copy_perimeter(const double2* in, double2* out, int ni, int nj, hipStream_t stream);
-hipError_t launch_perimeter_sub(const double2* in, const double2* h, double2* out, int ni, int nj, hipStream_t stream);   // out = in - h on the block's perimeter (tm_gmres.hip)
+hipError_t launch_perimeter_sub(const double2* in, const double2* h, double2* out, int ni, int nj, hipStream_t stream);   // out = in - h + out on the block's perimeter (tm_gmres.hip)
 // the perimeter values of f as Dirichlet data of a block's cycle: f_ring -= (D^-1 A)_ring,p f_p with the originals saved in `save` at the same
 // positions, and their restoration (tm_gmres.hip)
 hipError_t launch_ring_dirichlet(double2* f, const double2* X, const double2* PQ, double2* save, int ni, int nj, hipStream_t stream);

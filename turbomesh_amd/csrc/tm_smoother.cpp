@@ -248,6 +248,7 @@ void Smoother::create(const tm_mesh_desc* mesh, const tm_solver_opt* o, const tm
     // corrections inside every application -- microseconds beside two cycles)
     mg_perimeter_step = use_mg && (!topo.conns.empty() || !topo.bcs.empty());
     if (const char* e = std::getenv("TM_MG_PERIMETER_STEP")) mg_perimeter_step = mg_perimeter_step && std::atoi(e) != 0;
+    if (const char* e = std::getenv("TM_MG_PERIMETER_SWEEPS")) mg_perimeter_sweeps = std::max(1, std::atoi(e));
     mg_dirichlet = mg_perimeter_step;   // ... and the perimeter values as Dirichlet data in front of the cycles (block-local: no exchange)
     if (const char* e = std::getenv("TM_MG_DIRICHLET")) mg_dirichlet = mg_dirichlet && std::atoi(e) != 0;
     if (opt.inner == TM_INNER_GMRES) {   // w / z of GMRES.zig:27-38 in one vector, the basis v_0 .. v_m contiguous behind it
@@ -1147,15 +1148,21 @@ void Smoother::precondition(const double2* in, double2* out) {
     // the interior corrections just computed (block upper-triangular instead of block-diagonal: the rows of an interface see the
     // corrections of the first interior rows either side of it).  One perimeter-row launch and a subtraction per block; `t` is free
     // whenever a preconditioner application runs (picard_bicgstab) and lends its perimeter entries.
-    if (has_hooks) {   // the rows of an interface read the corrections of the neighbour's first interior rows: one more exchange per application
-        exchange(out);
-        exchange_finish();
-    }
-    HIPCHK(launch_edge_rows(edge, out, X, PQ, nullptr, t, 0.0, MODE_SCALED, DOT_NONE, nullptr, stream));
-    for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
-        const int64_t b = lp.owned_blocks[k];
-        const int64_t ls = lp.local_start[k];
-        HIPCHK(launch_perimeter_sub(in + ls, t + ls, out + ls, static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), stream));
+    // ... and then `mg_perimeter_sweeps - 1` Jacobi sweeps on the perimeter system itself (the rows are equilibrated: unit diagonal), whose
+    // couplings ALONG an interface and between the two copies of its nodes the first pass leaves out: with the perimeter rows applied to
+    // (e_I, e_p) the same two launches read e_p <- f_p - rows + e_p.  CPU prototype with exact interior solves: 41 / 39 / 54 iterations with
+    // the first pass alone, 26 / 28 / 39 with one sweep more, 23 / 28 / 35 with the perimeter system solved exactly.
+    for (int sweep = 0; sweep < mg_perimeter_sweeps; ++sweep) {
+        if (has_hooks) {   // the rows of an interface read the neighbour's corrections (first interior rows, then perimeter values too): an exchange per pass
+            exchange(out);
+            exchange_finish();
+        }
+        HIPCHK(launch_edge_rows(edge, out, X, PQ, nullptr, t, 0.0, MODE_SCALED, DOT_NONE, nullptr, stream));
+        for (size_t k = 0; k < lp.owned_blocks.size(); ++k) {
+            const int64_t b = lp.owned_blocks[k];
+            const int64_t ls = lp.local_start[k];
+            HIPCHK(launch_perimeter_sub(in + ls, t + ls, out + ls, static_cast<int>(topo.ni[b]), static_cast<int>(topo.nj[b]), stream));
+        }
     }
 }
 

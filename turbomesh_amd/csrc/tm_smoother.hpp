@@ -70,6 +70,7 @@ struct Smoother {
     bool use_mg = false;
     bool mg_perimeter_step = false;   // the preconditioner applies the perimeter rows to the interior corrections (precondition())
     bool mg_dirichlet = false;   // ... and hands the perimeter values to the cycles as Dirichlet data (precondition())
+    int mg_perimeter_sweeps = 2;   // passes of the perimeter rows behind the cycles: the first on (e_I, 0), the others Jacobi sweeps on the perimeter system
     void precondition(const double2* in, double2* out);
     double2* M = nullptr;           // X^(k+1) of a fused pair of relax sweeps (perimeter + first-interior ring only)
     double2* M2 = nullptr;          // coupled triples: X^(k+2) on the perimeter and in the zone next to sides whose perimeter rows move
