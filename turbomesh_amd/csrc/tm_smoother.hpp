@@ -70,6 +70,10 @@ struct Smoother {
     bool use_mg = false;
     bool mg_perimeter_step = false;   // the preconditioner applies the perimeter rows to the interior corrections (precondition())
     bool mg_dirichlet = false;   // ... and hands the perimeter values to the cycles as Dirichlet data (precondition())
+    // the cycles of a multi-block mesh run side by side: one stream per block (at most 8), forked from and joined to the handle's stream by events
+    std::vector<hipStream_t> mg_streams;
+    std::vector<hipEvent_t> mg_join;
+    hipEvent_t mg_fork = nullptr;
     int mg_perimeter_sweeps = 2;   // passes of the perimeter rows behind the cycles: the first on (e_I, 0), the others Jacobi sweeps on the perimeter system
     void precondition(const double2* in, double2* out);
     double2* M = nullptr;           // X^(k+1) of a fused pair of relax sweeps (perimeter + first-interior ring only)
