@@ -8,6 +8,8 @@ usage: worker.py <mode> <topology> <ni> <nj> <iterations> <out.json>
             krylov   -- Picard + BiCGStab, hooked recurrence with ncclAllReduce: bit-identical to the torch.distributed (gloo) hooks at
                         world 2, and within 1e-10 rms of the single-handle run
             gmres    -- the same with GMRES(30) as the inner solver (every Gram-Schmidt inner product is an all-reduce)
+            mg       -- the same with the multigrid-preconditioned BiCGStab (two more exchanges per preconditioner application: the perimeter rows
+                        applied to the neighbours' corrections)
   topology  strip | strip_rev | junction   (strip: `world` x $TM_WORKER_BLOCKS_PER_RANK blocks stacked in i; junction: configs.two_by_two, one block per rank)"""
 import json
 import os
@@ -44,7 +46,8 @@ def main():
     owner = [b // bpr for b in range(nb)]
     owned = [b for b in range(nb) if owner[b] == rank]
     opt = (solver.Option.hip(inner=solver.Inner.relax) if mode == "relax" else
-           solver.Option.hip(inner=solver.Inner.gmres, rtol=1e-13, max_inner=20000) if mode == "gmres" else solver.Option.hip(rtol=1e-13))
+           solver.Option.hip(inner=solver.Inner.gmres, rtol=1e-13, max_inner=20000) if mode == "gmres" else
+           solver.Option.hip(inner=solver.Inner.mg_bicgstab, rtol=1e-13) if mode == "mg" else solver.Option.hip(rtol=1e-13))
     mesh = build(set(owned))
     h = tmd.RcclHooks(mesh, owner=owner, rank=rank, world=world, option=opt)
     st = h.iterate(its)
@@ -53,7 +56,7 @@ def main():
     result = {"rank": rank, "world": world, "outer_iterations": int(st["outer_iterations"]), "inner_iterations": int(st["inner_iterations"])}
 
     other = None
-    if mode in ("krylov", "gmres"):   # the same job through the torch.distributed hooks (gloo: halo rows and scalars staged through the host)
+    if mode in ("krylov", "gmres", "mg"):   # the same job through the torch.distributed hooks (gloo: halo rows and scalars staged through the host)
         mesh_t = build(set(owned))
         ht = tmd.TorchHooks(mesh_t, owner=owner, rank=rank, world=world, option=opt)
         ht.iterate(its)

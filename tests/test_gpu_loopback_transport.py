@@ -118,11 +118,12 @@ def test_relax_sweeps_over_reversed_interfaces_and_the_junction_mesh(topology, w
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("mode", ["krylov", "gmres"])
+@pytest.mark.parametrize("mode", ["krylov", "gmres", "mg"])
 def test_krylov_path_over_tm_rccl_allreduce(mode, tmp_path):
     # Picard + BiCGStab (and GMRES(30): an all-reduce per Gram-Schmidt inner product) on two ranks: halo exchange per operator application +
     # ncclAllReduce of the reduction scalars, both issued by tm_rccl.cpp.  Two summands commute, so the run is bit-identical to the
-    # torch.distributed hooks; a single handle sums in another order: <= 1e-10 rms.
+    # torch.distributed hooks; a single handle sums in another order: <= 1e-10 rms.  "mg": the multigrid-preconditioned solve, whose perimeter step
+    # exchanges the corrections inside every preconditioner application (Smoother::precondition).
     assert _build()
     res = _worker(2, [mode, "strip", 40, 56, 2], _env(), tmp_path)
     assert res["bit_identical_to_torch_hooks"] is True, res
